@@ -1,0 +1,552 @@
+/*
+ * ife_oracle.c -- CPU restatement (plain C) of the reference's per-voxel Hessian
+ * feature path.  TEST INFRASTRUCTURE ONLY: see ife_oracle.h for who may load it
+ * and for the parity status of each part (eigen solver pinned by the reference's
+ * known-answer tests; ITK-wired stages "parity unpinned").
+ *
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (oracle/Makefile).
+ * -ffp-contract=off matters: the reference is built for generic x86-64 (no FMA),
+ * so every multiply and add below rounds separately, and the HIP path is built the
+ * same way so that it can reproduce these results bit for bit.
+ *
+ * All paths below are relative to /root/reference.
+ */
+#include "ife_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static int g_threads = 1;
+
+void ife_or_set_threads(int n) {
+  g_threads = n < 1 ? 1 : n;
+#ifdef _OPENMP
+  omp_set_num_threads(g_threads);
+#endif
+}
+int ife_or_get_threads(void) { return g_threads; }
+
+/* ------------------------------------------------------------------------- */
+/* a1: include/ife/Numerics/Symmetric3x3EigenvalueSolver.h:33-132             */
+/* ------------------------------------------------------------------------- */
+
+#define IFE_DIAG_SORT(T, ABS)                                                       \
+  /* :45-83 nested strict '>' tree; on ties the else arm wins */                     \
+  if (ABS(A11) > ABS(A22)) {                                                        \
+    if (ABS(A11) > ABS(A33)) {                                                      \
+      ev[0] = A11;                                                                  \
+      if (ABS(A22) > ABS(A33)) { ev[1] = A22; ev[2] = A33; }                        \
+      else                     { ev[1] = A33; ev[2] = A22; }                        \
+    } else { ev[0] = A33; ev[1] = A11; ev[2] = A22; }                               \
+  } else {                                                                          \
+    if (ABS(A22) > ABS(A33)) {                                                      \
+      ev[0] = A22;                                                                  \
+      if (ABS(A11) > ABS(A33)) { ev[1] = A11; ev[2] = A33; }                        \
+      else                     { ev[1] = A33; ev[2] = A11; }                        \
+    } else { ev[0] = A33; ev[1] = A22; ev[2] = A11; }                               \
+  }
+
+void ife_or_eig3_f64(const double A[6], double ev[3]) {
+  double A11 = A[0], A12 = A[1], A13 = A[2], A22 = A[3], A23 = A[4], A33 = A[5]; /* :37-42 */
+  double p = A12 * A12 + A13 * A13 + A23 * A23;                                   /* :44 */
+  if (p == 0) {
+    IFE_DIAG_SORT(double, fabs)
+  } else {
+    double q = (A11 + A22 + A33) / 3;                                             /* :85 */
+    p = (A11 - q) * (A11 - q) + (A22 - q) * (A22 - q) + (A33 - q) * (A33 - q) + 2 * p;
+    p = sqrt(p / 6);                                                              /* :88 */
+    double B11 = (A11 - q) / p, B12 = A12 / p, B13 = A13 / p;
+    double B22 = (A22 - q) / p, B23 = A23 / p, B33 = (A33 - q) / p;               /* :92-97 */
+    double r = (B11 * B22 * B33 + 2 * B12 * B13 * B23 - B23 * B23 * B11 - B13 * B13 * B22 -
+                B12 * B12 * B33) / 2.0;                                           /* :98-103 */
+    double phi;
+    if (r <= -1) phi = M_PI / 3;
+    else if (r >= 1) phi = 0;
+    else phi = acos(r) / 3;                                                       /* :107-116 */
+    ev[0] = q + 2 * p * cos(phi);
+    ev[2] = q + 2 * p * cos(phi + M_PI * (2.0 / 3.0));
+    ev[1] = 3 * q - ev[0] - ev[2];                                                /* :119-121 */
+    if (fabs(ev[0]) < fabs(ev[2])) { double t = ev[0]; ev[0] = ev[2]; ev[2] = t; } /* :123-125 */
+    if (fabs(ev[1]) < fabs(ev[2])) { double t = ev[1]; ev[1] = ev[2]; ev[2] = t; } /* :127-129 */
+  }
+}
+
+void ife_or_eig3_f32(const float A[6], float ev[3], int trig_mode) {
+  float A11 = A[0], A12 = A[1], A13 = A[2], A22 = A[3], A23 = A[4], A33 = A[5];
+  float p = A12 * A12 + A13 * A13 + A23 * A23;
+  if (p == 0) {
+    IFE_DIAG_SORT(float, fabsf)
+  } else {
+    float q = (A11 + A22 + A33) / 3;
+    p = (A11 - q) * (A11 - q) + (A22 - q) * (A22 - q) + (A33 - q) * (A33 - q) + 2 * p;
+    /* :88 unqualified sqrt: ::sqrt(double) with <cmath> only, the float overload
+     * once <math.h> has pulled std::sqrt into the global namespace. */
+    if (trig_mode == IFE_OR_TRIG_CMATH) p = (float)sqrt((double)(p / 6));
+    else p = sqrtf(p / 6);
+    float B11 = (A11 - q) / p, B12 = A12 / p, B13 = A13 / p;
+    float B22 = (A22 - q) / p, B23 = A23 / p, B33 = (A33 - q) / p;
+    /* float expression, then "/ 2.0" in double (exact), rounded back to float */
+    float r = (float)((double)(B11 * B22 * B33 + 2 * B12 * B13 * B23 - B23 * B23 * B11 -
+                               B13 * B13 * B22 - B12 * B12 * B33) / 2.0);
+    float phi;
+    if (r <= -1) phi = (float)(M_PI / 3);
+    else if (r >= 1) phi = 0;
+    else if (trig_mode == IFE_OR_TRIG_CMATH) phi = (float)(acos((double)r) / 3);
+    else phi = acosf(r) / 3;
+    if (trig_mode == IFE_OR_TRIG_CMATH)
+      ev[0] = (float)((double)q + (double)(2 * p) * cos((double)phi));
+    else
+      ev[0] = q + 2 * p * cosf(phi);
+    /* phi + M_PI*(2.0/3.0) is double in both contexts, so cos is the double one */
+    ev[2] = (float)((double)q + (double)(2 * p) * cos((double)phi + M_PI * (2.0 / 3.0)));
+    ev[1] = 3 * q - ev[0] - ev[2];
+    if (fabsf(ev[0]) < fabsf(ev[2])) { float t = ev[0]; ev[0] = ev[2]; ev[2] = t; }
+    if (fabsf(ev[1]) < fabsf(ev[2])) { float t = ev[1]; ev[1] = ev[2]; ev[2] = t; }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a2: include/ife/Numerics/EigenvalueFeaturesFunctor.h:20-31                  */
+/* ------------------------------------------------------------------------- */
+void ife_or_eigfeat_f64(const double A[6], double f[6]) {
+  double ev[3];
+  ife_or_eig3_f64(A, ev);
+  f[0] = ev[0]; f[1] = ev[1]; f[2] = ev[2];
+  f[3] = ev[0] + ev[1] + ev[2];
+  f[4] = ev[0] * ev[1] * ev[2];
+  f[5] = sqrt(ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2]);
+}
+
+void ife_or_eigfeat_f32(const float A[6], float f[6], int trig_mode) {
+  float ev[3];
+  ife_or_eig3_f32(A, ev, trig_mode);
+  f[0] = ev[0]; f[1] = ev[1]; f[2] = ev[2];
+  f[3] = ev[0] + ev[1] + ev[2];
+  f[4] = ev[0] * ev[1] * ev[2];
+  f[5] = sqrtf(ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2]); /* std::sqrt(float) */
+}
+
+void ife_or_eig3_batch_f32(const float *A6, int64_t n, float *ev3, int trig_mode) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) ife_or_eig3_f32(A6 + 6 * i, ev3 + 3 * i, trig_mode);
+}
+void ife_or_eigfeat_batch_f32(const float *A6, int64_t n, float *f6, int trig_mode) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) ife_or_eigfeat_f32(A6 + 6 * i, f6 + 6 * i, trig_mode);
+}
+void ife_or_eig3_batch_f64(const double *A6, int64_t n, double *ev3) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) ife_or_eig3_f64(A6 + 6 * i, ev3 + 3 * i);
+}
+
+/* ------------------------------------------------------------------------- */
+/* a4 pieces [ITK-upstream, parity unpinned]: itk::RecursiveGaussianImageFilter */
+/* ::SetUp / ComputeNCoefficients / ComputeDCoefficients /                      */
+/* ComputeRemainingCoefficients (ZeroOrder, NormalizeAcrossScale off), called   */
+/* through NormalizedGaussianConvolutionImageFilter.hxx:51-55.                  */
+/* ------------------------------------------------------------------------- */
+int ife_or_gauss_coeffs_zero_order(double sigma, double spacing, ife_or_gauss_coeffs *c) {
+  const double A1 = 1.3530, B1 = 1.8151, W1 = 0.6681, L1 = -1.3932;
+  const double A2 = -0.3531, B2 = 0.0902, W2 = 2.0787, L2 = -1.3732;
+  if (spacing < 0.0) spacing = -spacing;
+  if (spacing < 1e-8) return -1;
+  const double sigmad = sigma / spacing;
+
+  {
+    const double Cos1 = cos(W1 / sigmad), Cos2 = cos(W2 / sigmad);
+    const double Exp1 = exp(L1 / sigmad), Exp2 = exp(L2 / sigmad);
+    c->D4 = Exp1 * Exp1 * Exp2 * Exp2;
+    c->D3 = -2 * Cos1 * Exp1 * Exp2 * Exp2;
+    c->D3 += -2 * Cos2 * Exp2 * Exp1 * Exp1;
+    c->D2 = 4 * Cos2 * Cos1 * Exp1 * Exp2;
+    c->D2 += Exp1 * Exp1 + Exp2 * Exp2;
+    c->D1 = -2 * (Exp2 * Cos2 + Exp1 * Cos1);
+  }
+  const double SD = 1.0 + c->D1 + c->D2 + c->D3 + c->D4;
+  double SN;
+  {
+    const double Sin1 = sin(W1 / sigmad), Sin2 = sin(W2 / sigmad);
+    const double Cos1 = cos(W1 / sigmad), Cos2 = cos(W2 / sigmad);
+    const double Exp1 = exp(L1 / sigmad), Exp2 = exp(L2 / sigmad);
+    c->N0 = A1 + A2;
+    c->N1 = Exp2 * (B2 * Sin2 - (A2 + 2 * A1) * Cos2);
+    c->N1 += Exp1 * (B1 * Sin1 - (A1 + 2 * A2) * Cos1);
+    c->N2 = (A1 + A2) * Cos2 * Cos1;
+    c->N2 -= B1 * Cos2 * Sin1 + B2 * Cos1 * Sin2;
+    c->N2 *= 2 * Exp1 * Exp2;
+    c->N2 += A2 * Exp1 * Exp1 + A1 * Exp2 * Exp2;
+    c->N3 = Exp2 * Exp1 * Exp1 * (B2 * Sin2 - A2 * Cos2);
+    c->N3 += Exp1 * Exp2 * Exp2 * (B1 * Sin1 - A1 * Cos1);
+    SN = c->N0 + c->N1 + c->N2 + c->N3;
+  }
+  const double alpha0 = 2 * SN / SD - c->N0;
+  c->N0 *= 1.0 / alpha0;
+  c->N1 *= 1.0 / alpha0;
+  c->N2 *= 1.0 / alpha0;
+  c->N3 *= 1.0 / alpha0;
+
+  /* symmetric case */
+  c->M1 = c->N1 - c->D1 * c->N0;
+  c->M2 = c->N2 - c->D2 * c->N0;
+  c->M3 = c->N3 - c->D3 * c->N0;
+  c->M4 = -c->D4 * c->N0;
+
+  /* edge-extension boundary coefficients */
+  const double SN2 = c->N0 + c->N1 + c->N2 + c->N3;
+  const double SM2 = c->M1 + c->M2 + c->M3 + c->M4;
+  const double SD2 = 1.0 + c->D1 + c->D2 + c->D3 + c->D4;
+  c->BN1 = c->D1 * SN2 / SD2;
+  c->BN2 = c->D2 * SN2 / SD2;
+  c->BN3 = c->D3 * SN2 / SD2;
+  c->BN4 = c->D4 * SN2 / SD2;
+  c->BM1 = c->D1 * SM2 / SD2;
+  c->BM2 = c->D2 * SM2 / SD2;
+  c->BM3 = c->D3 * SM2 / SD2;
+  c->BM4 = c->D4 * SM2 / SD2;
+  return 0;
+}
+
+/* [ITK-upstream] itk::RecursiveSeparableImageFilter::FilterDataArray, RealType=double.
+ * ln must be >= 4 (ITK throws otherwise). */
+void ife_or_iir_line(const double *data, double *outs, double *s, int64_t ln,
+                     const ife_or_gauss_coeffs *c) {
+  const double N0 = c->N0, N1 = c->N1, N2 = c->N2, N3 = c->N3;
+  const double D1 = c->D1, D2 = c->D2, D3 = c->D3, D4 = c->D4;
+  const double M1 = c->M1, M2 = c->M2, M3 = c->M3, M4 = c->M4;
+  const double BN1 = c->BN1, BN2 = c->BN2, BN3 = c->BN3, BN4 = c->BN4;
+  const double BM1 = c->BM1, BM2 = c->BM2, BM3 = c->BM3, BM4 = c->BM4;
+
+  const double outV1 = data[0];
+  s[0] = outV1 * N0 + outV1 * N1 + outV1 * N2 + outV1 * N3;
+  s[1] = data[1] * N0 + outV1 * N1 + outV1 * N2 + outV1 * N3;
+  s[2] = data[2] * N0 + data[1] * N1 + outV1 * N2 + outV1 * N3;
+  s[3] = data[3] * N0 + data[2] * N1 + data[1] * N2 + outV1 * N3;
+
+  s[0] -= outV1 * BN1 + outV1 * BN2 + outV1 * BN3 + outV1 * BN4;
+  s[1] -= s[0] * D1 + outV1 * BN2 + outV1 * BN3 + outV1 * BN4;
+  s[2] -= s[1] * D1 + s[0] * D2 + outV1 * BN3 + outV1 * BN4;
+  s[3] -= s[2] * D1 + s[1] * D2 + s[0] * D3 + outV1 * BN4;
+
+  for (int64_t i = 4; i < ln; i++) {
+    s[i] = data[i] * N0 + data[i - 1] * N1 + data[i - 2] * N2 + data[i - 3] * N3;
+    s[i] -= s[i - 1] * D1 + s[i - 2] * D2 + s[i - 3] * D3 + s[i - 4] * D4;
+  }
+  for (int64_t i = 0; i < ln; i++) outs[i] = s[i];
+
+  const double outV2 = data[ln - 1];
+  s[ln - 1] = outV2 * M1 + outV2 * M2 + outV2 * M3 + outV2 * M4;
+  s[ln - 2] = data[ln - 1] * M1 + outV2 * M2 + outV2 * M3 + outV2 * M4;
+  s[ln - 3] = data[ln - 2] * M1 + data[ln - 1] * M2 + outV2 * M3 + outV2 * M4;
+  s[ln - 4] = data[ln - 3] * M1 + data[ln - 2] * M2 + data[ln - 1] * M3 + outV2 * M4;
+
+  s[ln - 1] -= outV2 * BM1 + outV2 * BM2 + outV2 * BM3 + outV2 * BM4;
+  s[ln - 2] -= s[ln - 1] * D1 + outV2 * BM2 + outV2 * BM3 + outV2 * BM4;
+  s[ln - 3] -= s[ln - 2] * D1 + s[ln - 1] * D2 + outV2 * BM3 + outV2 * BM4;
+  s[ln - 4] -= s[ln - 3] * D1 + s[ln - 2] * D2 + s[ln - 1] * D3 + outV2 * BM4;
+
+  for (int64_t i = ln - 4; i > 0; i--) {
+    s[i - 1] = data[i] * M1 + data[i + 1] * M2 + data[i + 2] * M3 + data[i + 3] * M4;
+    s[i - 1] -= s[i] * D1 + s[i + 1] * D2 + s[i + 2] * D3 + s[i + 3] * D4;
+  }
+  for (int64_t i = 0; i < ln; i++) outs[i] += s[i];
+}
+
+static int64_t axis_len(const ife_or_dims *d, int a) { return a == 0 ? d->nx : a == 1 ? d->ny : d->nz; }
+static double axis_sp(const ife_or_dims *d, int a) { return a == 0 ? d->sx : a == 1 ? d->sy : d->sz; }
+static int64_t axis_stride(const ife_or_dims *d, int a) {
+  return a == 0 ? 1 : a == 1 ? d->nx : d->nx * d->ny;
+}
+
+/* [ITK-upstream] RecursiveSeparableImageFilter::ThreadedGenerateData: copy a line to
+ * double, FilterDataArray, cast each sample back to the (float) output pixel type. */
+int ife_or_recursive_gaussian_axis(const float *in, float *out, const ife_or_dims *d, int axis,
+                                   double sigma) {
+  const int64_t ln = axis_len(d, axis);
+  if (ln < 4) return -2;
+  ife_or_gauss_coeffs c;
+  if (ife_or_gauss_coeffs_zero_order(sigma, axis_sp(d, axis), &c)) return -1;
+  const int64_t st = axis_stride(d, axis);
+  const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+  const int64_t n1 = axis_len(d, a1), n2 = axis_len(d, a2);
+  const int64_t s1 = axis_stride(d, a1), s2 = axis_stride(d, a2);
+  int err = 0;
+#pragma omp parallel
+  {
+    double *buf = (double *)malloc(sizeof(double) * 3 * (size_t)ln);
+    if (!buf) {
+#pragma omp atomic write
+      err = 1;
+    } else {
+      double *inps = buf, *outs = buf + ln, *scr = buf + 2 * ln;
+#pragma omp for collapse(2) schedule(static)
+      for (int64_t j = 0; j < n2; ++j)
+        for (int64_t i = 0; i < n1; ++i) {
+          const int64_t base = i * s1 + j * s2;
+          for (int64_t k = 0; k < ln; ++k) inps[k] = in[base + k * st];
+          ife_or_iir_line(inps, outs, scr, ln, &c);
+          for (int64_t k = 0; k < ln; ++k) out[base + k * st] = (float)outs[k];
+        }
+      free(buf);
+    }
+  }
+  return err ? -3 : 0;
+}
+
+/* [ITK-upstream] itk::SmoothingRecursiveGaussianImageFilter: first filter along
+ * direction ImageDimension-1 (Z), then directions 0 (X) and 1 (Y); float images
+ * between the axis passes, final cast to float. */
+int ife_or_smoothing_recursive_gaussian(const float *in, float *out, const ife_or_dims *d,
+                                        double sigma) {
+  const int64_t n = d->nx * d->ny * d->nz;
+  float *tmp = (float *)malloc(sizeof(float) * (size_t)n);
+  if (!tmp) return -3;
+  int rc = ife_or_recursive_gaussian_axis(in, tmp, d, 2, sigma);
+  if (!rc) rc = ife_or_recursive_gaussian_axis(tmp, out, d, 0, sigma);
+  if (!rc) {
+    memcpy(tmp, out, sizeof(float) * (size_t)n);
+    rc = ife_or_recursive_gaussian_axis(tmp, out, d, 1, sigma);
+  }
+  free(tmp);
+  return rc;
+}
+
+/* a4: NormalizedGaussianConvolutionImageFilter.hxx:40-63.
+ * Multiply (:48-49), two smoothings (:51-55), Divide (:57-61) with
+ * [ITK-upstream] Functor::Div: B != 0 ? A / B : NumericTraits<float>::max(). */
+int ife_or_normalized_gaussian_convolution(const float *image, const float *certainty,
+                                           float *out, const ife_or_dims *d, double sigma) {
+  const int64_t n = d->nx * d->ny * d->nz;
+  float *tc = (float *)malloc(sizeof(float) * (size_t)n);
+  float *g1 = (float *)malloc(sizeof(float) * (size_t)n);
+  float *g2 = (float *)malloc(sizeof(float) * (size_t)n);
+  int rc = (tc && g1 && g2) ? 0 : -3;
+  if (!rc) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) tc[i] = image[i] * certainty[i];
+    rc = ife_or_smoothing_recursive_gaussian(tc, g1, d, sigma);
+  }
+  if (!rc) rc = ife_or_smoothing_recursive_gaussian(certainty, g2, d, sigma);
+  if (!rc) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) out[i] = (g2[i] != 0.0f) ? g1[i] / g2[i] : FLT_MAX;
+  }
+  free(tc); free(g1); free(g2);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a3 pieces [ITK-upstream, parity unpinned]: itk::DerivativeOperator           */
+/* ::GenerateCoefficients, FlipAxes, ScaleCoefficients and the                  */
+/* NeighborhoodOperatorImageFilter inner product (double accumulate, start at   */
+/* 0, ZeroFluxNeumann = index clamp), result cast to float.                     */
+/* ------------------------------------------------------------------------- */
+static void derivative_operator(int order, double scale, double coeff[3]) {
+  /* w = 2*((order+1)/2)+1 = 3 for order 1 and 2 */
+  coeff[0] = 0.0; coeff[1] = 1.0; coeff[2] = 0.0;
+  const int w = 3;
+  double previous, next;
+  int i, j;
+  for (i = 0; i < order / 2; i++) {
+    previous = coeff[1] - 2 * coeff[0];
+    for (j = 1; j < w - 1; j++) {
+      next = coeff[j - 1] + coeff[j + 1] - 2 * coeff[j];
+      coeff[j - 1] = previous;
+      previous = next;
+    }
+    next = coeff[j - 1] - 2 * coeff[j];
+    coeff[j - 1] = previous;
+    coeff[j] = next;
+  }
+  for (i = 0; i < order % 2; i++) {
+    previous = 0.5 * coeff[1];
+    for (j = 1; j < w - 1; j++) {
+      next = -0.5 * coeff[j - 1] + 0.5 * coeff[j + 1];
+      coeff[j - 1] = previous;
+      previous = next;
+    }
+    next = -0.5 * coeff[j - 1];
+    coeff[j - 1] = previous;
+    coeff[j] = next;
+  }
+  /* FlipAxes */
+  double t = coeff[0]; coeff[0] = coeff[2]; coeff[2] = t;
+  /* ScaleCoefficients */
+  for (i = 0; i < 3; ++i) coeff[i] = coeff[i] * scale;
+}
+
+static double deriv_scale(double spacing, int order, int dscale_mode) {
+  double s = 1.0 / spacing;
+  if (dscale_mode == IFE_OR_DSCALE_POW && order == 2) s = s * s;
+  return s;
+}
+
+static inline int64_t clampi(int64_t v, int64_t hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+int ife_or_derivative(const float *in, float *out, const ife_or_dims *d, int order,
+                      int direction, int dscale_mode) {
+  if (order < 1 || order > 2 || direction < 0 || direction > 2) return -1;
+  const double sp = axis_sp(d, direction);
+  if (sp == 0.0) return -1;
+  double co[3];
+  derivative_operator(order, deriv_scale(sp, order, dscale_mode), co);
+  const int64_t nx = d->nx, ny = d->ny, nz = d->nz;
+  const int64_t st = axis_stride(d, direction), len = axis_len(d, direction);
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int64_t z = 0; z < nz; ++z)
+    for (int64_t y = 0; y < ny; ++y)
+      for (int64_t x = 0; x < nx; ++x) {
+        const int64_t idx = x + nx * (y + ny * z);
+        const int64_t p = direction == 0 ? x : direction == 1 ? y : z;
+        const int64_t im = idx + (clampi(p - 1, len - 1) - p) * st;
+        const int64_t ip = idx + (clampi(p + 1, len - 1) - p) * st;
+        double sum = 0.0;
+        sum += co[0] * (double)in[im];
+        sum += co[1] * (double)in[idx];
+        sum += co[2] * (double)in[ip];
+        out[idx] = (float)sum;
+      }
+  return 0;
+}
+
+/* a3: Hessian3DImageFilter.hxx:13-60 wiring; component order xx,xy,xz,yy,yz,zz (:54-59) */
+int ife_or_hessian3d(const float *in, float *out6, const ife_or_dims *d, int dscale_mode) {
+  const int64_t n = d->nx * d->ny * d->nz;
+  float *t = (float *)malloc(sizeof(float) * (size_t)n * 3);
+  if (!t) return -3;
+  float *dx = t, *dy = t + n, *c = t + 2 * n;
+  int rc = ife_or_derivative(in, dx, d, 1, 0, dscale_mode);           /* :31-34 */
+  if (!rc) rc = ife_or_derivative(in, dy, d, 1, 1, dscale_mode);      /* :35-37 */
+  struct { const float *src; int order, dir, comp; } plan[6] = {
+      {in, 2, 0, 0},  /* Dxx :19-22 */
+      {dx, 1, 1, 1},  /* Dxy = D_y(Dx) :39-43 */
+      {dx, 1, 2, 2},  /* Dxz = D_z(Dx) :44-47 */
+      {in, 2, 1, 3},  /* Dyy */
+      {dy, 1, 2, 4},  /* Dyz = D_z(Dy) :48-51 */
+      {in, 2, 2, 5},  /* Dzz */
+  };
+  for (int k = 0; k < 6 && !rc; ++k) {
+    rc = ife_or_derivative(plan[k].src, c, d, plan[k].order, plan[k].dir, dscale_mode);
+    if (!rc) {
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) out6[i * 6 + plan[k].comp] = c[i];
+    }
+  }
+  free(t);
+  return rc;
+}
+
+/* [ITK-upstream] itk::GradientMagnitudeImageFilter::ThreadedGenerateData:
+ * RealType=double, per axis g = inner product with the order-1 operator scaled by
+ * 1/spacing, a += g*g in axis order 0,1,2, out = float(std::sqrt(a)). */
+int ife_or_gradient_magnitude(const float *in, float *out, const ife_or_dims *d) {
+  double co[3][3];
+  for (int a = 0; a < 3; ++a) {
+    if (axis_sp(d, a) == 0.0) return -1;
+    derivative_operator(1, 1.0 / axis_sp(d, a), co[a]);
+  }
+  const int64_t nx = d->nx, ny = d->ny, nz = d->nz;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int64_t z = 0; z < nz; ++z)
+    for (int64_t y = 0; y < ny; ++y)
+      for (int64_t x = 0; x < nx; ++x) {
+        const int64_t idx = x + nx * (y + ny * z);
+        const int64_t pos[3] = {x, y, z};
+        double a = 0.0;
+        for (int ax = 0; ax < 3; ++ax) {
+          const int64_t st = axis_stride(d, ax), len = axis_len(d, ax);
+          const int64_t im = idx + (clampi(pos[ax] - 1, len - 1) - pos[ax]) * st;
+          const int64_t ip = idx + (clampi(pos[ax] + 1, len - 1) - pos[ax]) * st;
+          double g = 0.0;
+          g += co[ax][0] * (double)in[im];
+          g += co[ax][1] * (double)in[idx];
+          g += co[ax][2] * (double)in[ip];
+          a += g * g;
+        }
+        out[idx] = (float)sqrt(a);
+      }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a5: ImageToEmphysemaFeaturesFilter.hxx:15-55 (wiring), :99-121 (GenerateData) */
+/* out comps: [S, |grad S|, ev1, ev2, ev3, LoG, product, Frobenius], each through */
+/* MaskImageFilter (mask != 0 ? v : 0).                                          */
+/* ------------------------------------------------------------------------- */
+int ife_or_emphysema_features(const float *image, const uint8_t *mask, float *out8,
+                              const ife_or_dims *d, double sigma, int trig_mode,
+                              int dscale_mode) {
+  const int64_t n = d->nx * d->ny * d->nz;
+  float *cert = (float *)malloc(sizeof(float) * (size_t)n);
+  float *S = (float *)malloc(sizeof(float) * (size_t)n);
+  float *G = (float *)malloc(sizeof(float) * (size_t)n);
+  float *H = (float *)malloc(sizeof(float) * (size_t)n * 6);
+  int rc = (cert && S && G && H) ? 0 : -3;
+  if (!rc) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) cert[i] = (float)mask[i]; /* CastImageFilter .hxx:21,110 */
+    rc = ife_or_normalized_gaussian_convolution(image, cert, S, d, sigma);
+  }
+  if (!rc) rc = ife_or_gradient_magnitude(S, G, d);
+  if (!rc) rc = ife_or_hessian3d(S, H, d, dscale_mode);
+  if (!rc) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+      float f[6];
+      ife_or_eigfeat_f32(H + 6 * i, f, trig_mode); /* every voxel, also outside the mask */
+      float *o = out8 + 8 * i;
+      if (mask[i] != 0) {
+        o[0] = S[i]; o[1] = G[i];
+        for (int k = 0; k < 6; ++k) o[2 + k] = f[k];
+      } else {
+        for (int k = 0; k < 8; ++k) o[k] = 0.0f;
+      }
+    }
+  }
+  free(cert); free(S); free(G); free(H);
+  return rc;
+}
+
+/* a6: tools/FiniteDifference_HessianFeatures.cxx:126-229 (dead tool); normative
+ * definition = a3 o a2 o mask, WITHOUT the :155 direction bug.  mask==0 -> six 0. */
+int ife_or_fd_hessian_features(const float *image, const uint8_t *mask, float *out6,
+                               const ife_or_dims *d, int trig_mode, int dscale_mode) {
+  const int64_t n = d->nx * d->ny * d->nz;
+  int rc = ife_or_hessian3d(image, out6, d, dscale_mode);
+  if (rc) return rc;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    float *o = out6 + 6 * i;
+    if (mask && mask[i] == 0) {
+      for (int k = 0; k < 6; ++k) o[k] = 0.0f;
+    } else {
+      float f[6];
+      ife_or_eigfeat_f32(o, f, trig_mode);
+      for (int k = 0; k < 6; ++k) o[k] = f[k];
+    }
+  }
+  return 0;
+}
+
+/* a7: tools/FiniteDifference_GradientFeatures.cxx:104-113; the mask is a float image there */
+int ife_or_fd_gradient_features(const float *image, const float *mask, float *out,
+                                const ife_or_dims *d) {
+  const int64_t n = d->nx * d->ny * d->nz;
+  int rc = ife_or_gradient_magnitude(image, out, d);
+  if (rc) return rc;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i)
+    if (mask[i] == 0.0f) out[i] = 0.0f;
+  return 0;
+}
+
+/* a8: tools/MaskedImageFilter.cxx:75-93 */
+void ife_or_mask_image_f64(const double *image, const double *mask, double outside, double *out,
+                           int64_t n) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) out[i] = (mask[i] != 0.0) ? image[i] : outside;
+}

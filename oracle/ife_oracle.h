@@ -1,0 +1,105 @@
+/*
+ * ife_oracle.h -- CPU restatement of the per-voxel Hessian feature path of
+ * orting/image-feature-extraction.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (libife_hip.so) never links, loads or calls
+ * anything in oracle/.
+ *
+ * Parity status
+ *   - eigen solver / feature functor (a1, a2): PINNED by the reference's own
+ *     seven known-answer cases, test/Symmetric3x3EigenvalueSolverTest.cxx:48-90
+ *     (committed as tests/golden/eigen_kat.json).
+ *   - everything wired from ITK classes (a3..a9: recursive Gaussian, divide,
+ *     derivative operators, gradient magnitude, mask): PARITY UNPINNED.  ITK is
+ *     a third-party dependency of the reference (find_package(ITK) with no
+ *     version, CMakeLists.txt:14-16) that is absent from /root/reference and from
+ *     this image; the reference holds no test or fixture at that boundary.  The
+ *     restatement follows the published ITK 4.x algorithms named at each function.
+ *
+ * Layout: volumes are x-fastest (index = x + nx*(y + ny*z)), as itk::Image
+ * buffers.  Vector outputs are interleaved [voxel*ncomp + c] as itk::VectorImage.
+ */
+#ifndef IFE_ORACLE_H
+#define IFE_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* trig_mode for the float solver (SURVEY TL;DR item 5): unqualified sqrt/acos/cos
+ * in Symmetric3x3EigenvalueSolver.h:88,115,119-120 bind to the double C functions
+ * when only <cmath> is visible (mode 0) and to the float overloads when <math.h>
+ * is visible too (mode 1). */
+enum { IFE_OR_TRIG_CMATH = 0, IFE_OR_TRIG_MATH_H = 1 };
+
+/* ITK DerivativeImageFilter scales the operator by 1/spacing once, whatever the
+ * order (mode 0, upstream itkDerivativeImageFilter.hxx); mode 1 scales by
+ * 1/spacing^order.  Identical for unit spacing. */
+enum { IFE_OR_DSCALE_ITK = 0, IFE_OR_DSCALE_POW = 1 };
+
+typedef struct {
+  int64_t nx, ny, nz;
+  double sx, sy, sz;
+} ife_or_dims;
+
+typedef struct {
+  double N0, N1, N2, N3;
+  double D1, D2, D3, D4;
+  double M1, M2, M3, M4;
+  double BN1, BN2, BN3, BN4;
+  double BM1, BM2, BM3, BM4;
+} ife_or_gauss_coeffs;
+
+void ife_or_set_threads(int n);
+int ife_or_get_threads(void);
+
+/* a1: Symmetric3x3EigenvalueSolver<T>::operator() */
+void ife_or_eig3_f64(const double A[6], double ev[3]);
+void ife_or_eig3_f32(const float A[6], float ev[3], int trig_mode);
+/* a2: EigenvalueFeaturesFunctor<T>::operator() */
+void ife_or_eigfeat_f64(const double A[6], double f[6]);
+void ife_or_eigfeat_f32(const float A[6], float f[6], int trig_mode);
+void ife_or_eig3_batch_f32(const float *A6, int64_t n, float *ev3, int trig_mode);
+void ife_or_eigfeat_batch_f32(const float *A6, int64_t n, float *f6, int trig_mode);
+void ife_or_eig3_batch_f64(const double *A6, int64_t n, double *ev3);
+
+/* a4 pieces: itk::RecursiveGaussianImageFilter (ZeroOrder) */
+int ife_or_gauss_coeffs_zero_order(double sigma, double spacing, ife_or_gauss_coeffs *c);
+void ife_or_iir_line(const double *data, double *outs, double *scratch, int64_t ln,
+                     const ife_or_gauss_coeffs *c);
+int ife_or_recursive_gaussian_axis(const float *in, float *out, const ife_or_dims *d,
+                                   int axis, double sigma);
+int ife_or_smoothing_recursive_gaussian(const float *in, float *out, const ife_or_dims *d,
+                                        double sigma);
+/* a4: NormalizedGaussianConvolutionImageFilter */
+int ife_or_normalized_gaussian_convolution(const float *image, const float *certainty,
+                                           float *out, const ife_or_dims *d, double sigma);
+
+/* a3 pieces: itk::DerivativeImageFilter */
+int ife_or_derivative(const float *in, float *out, const ife_or_dims *d, int order,
+                      int direction, int dscale_mode);
+/* a3: Hessian3DImageFilter, out interleaved 6 comps xx,xy,xz,yy,yz,zz */
+int ife_or_hessian3d(const float *in, float *out6, const ife_or_dims *d, int dscale_mode);
+/* itk::GradientMagnitudeImageFilter */
+int ife_or_gradient_magnitude(const float *in, float *out, const ife_or_dims *d);
+
+/* a5: ImageToEmphysemaFeaturesFilter, one sigma; out interleaved 8 comps */
+int ife_or_emphysema_features(const float *image, const uint8_t *mask, float *out8,
+                              const ife_or_dims *d, double sigma, int trig_mode,
+                              int dscale_mode);
+/* a6: FiniteDifference_HessianFeatures body (normative a3 o a2 o mask); out interleaved 6 */
+int ife_or_fd_hessian_features(const float *image, const uint8_t *mask, float *out6,
+                               const ife_or_dims *d, int trig_mode, int dscale_mode);
+/* a7: FiniteDifference_GradientFeatures body */
+int ife_or_fd_gradient_features(const float *image, const float *mask, float *out,
+                                const ife_or_dims *d);
+/* a8: MaskedImageFilter tool body (double pixels) */
+void ife_or_mask_image_f64(const double *image, const double *mask, double outside,
+                           double *out, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

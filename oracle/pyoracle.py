@@ -1,0 +1,211 @@
+"""ctypes binding of the CPU oracle (oracle/libife_oracle.so).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg; the product package never imports this module.
+Function-by-function citations of the reference live in ``ife_oracle.c``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libife_oracle.so")
+
+TRIG_CMATH = 0
+TRIG_MATH_H = 1
+DSCALE_ITK = 0
+DSCALE_POW = 1
+
+
+class Dims(C.Structure):
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("nz", C.c_int64),
+                ("sx", C.c_double), ("sy", C.c_double), ("sz", C.c_double)]
+
+
+class GaussCoeffs(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "N0", "N1", "N2", "N3", "D1", "D2", "D3", "D4", "M1", "M2", "M3", "M4",
+        "BN1", "BN2", "BN3", "BN4", "BM1", "BM2", "BM3", "BM4")]
+
+
+def build():
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.ife_or_get_threads.restype = C.c_int
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _dims(shape_zyx, spacing_xyz=(1.0, 1.0, 1.0)):
+    nz, ny, nx = shape_zyx
+    return Dims(nx, ny, nz, *[float(s) for s in spacing_xyz])
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise RuntimeError("oracle %s failed rc=%d" % (what, rc))
+
+
+def set_threads(n):
+    lib().ife_or_set_threads(int(n))
+
+
+def eig3(A6, trig_mode=TRIG_CMATH):
+    """A6: (..., 6) float32 or float64 -> (..., 3) eigenvalues, |.| descending."""
+    A6 = np.ascontiguousarray(A6)
+    n = A6.size // 6
+    if A6.dtype == np.float64:
+        out = np.empty(A6.shape[:-1] + (3,), np.float64)
+        lib().ife_or_eig3_batch_f64(_p(A6, C.c_double), C.c_int64(n), _p(out, C.c_double))
+    else:
+        A6 = np.ascontiguousarray(A6, np.float32)
+        out = np.empty(A6.shape[:-1] + (3,), np.float32)
+        lib().ife_or_eig3_batch_f32(_p(A6, C.c_float), C.c_int64(n), _p(out, C.c_float),
+                                    C.c_int(trig_mode))
+    return out
+
+
+def eigfeat(A6, trig_mode=TRIG_CMATH):
+    A6 = np.ascontiguousarray(A6, np.float32)
+    n = A6.size // 6
+    out = np.empty(A6.shape[:-1] + (6,), np.float32)
+    lib().ife_or_eigfeat_batch_f32(_p(A6, C.c_float), C.c_int64(n), _p(out, C.c_float),
+                                   C.c_int(trig_mode))
+    return out
+
+
+def gauss_coeffs(sigma, spacing=1.0):
+    c = GaussCoeffs()
+    _chk(lib().ife_or_gauss_coeffs_zero_order(C.c_double(sigma), C.c_double(spacing), C.byref(c)),
+         "gauss_coeffs")
+    return c
+
+
+def iir_line(data, sigma, spacing=1.0):
+    data = np.ascontiguousarray(data, np.float64)
+    c = gauss_coeffs(sigma, spacing)
+    out = np.empty_like(data)
+    scr = np.empty_like(data)
+    lib().ife_or_iir_line(_p(data, C.c_double), _p(out, C.c_double), _p(scr, C.c_double),
+                          C.c_int64(data.size), C.byref(c))
+    return out
+
+
+def recursive_gaussian_axis(vol, axis_xyz, sigma, spacing=(1.0, 1.0, 1.0)):
+    vol = np.ascontiguousarray(vol, np.float32)
+    out = np.empty_like(vol)
+    d = _dims(vol.shape, spacing)
+    _chk(lib().ife_or_recursive_gaussian_axis(_p(vol, C.c_float), _p(out, C.c_float), C.byref(d),
+                                              C.c_int(axis_xyz), C.c_double(sigma)), "iir axis")
+    return out
+
+
+def smoothing_recursive_gaussian(vol, sigma, spacing=(1.0, 1.0, 1.0)):
+    vol = np.ascontiguousarray(vol, np.float32)
+    out = np.empty_like(vol)
+    d = _dims(vol.shape, spacing)
+    _chk(lib().ife_or_smoothing_recursive_gaussian(_p(vol, C.c_float), _p(out, C.c_float),
+                                                   C.byref(d), C.c_double(sigma)), "smoothing")
+    return out
+
+
+def normalized_gaussian_convolution(image, certainty, sigma, spacing=(1.0, 1.0, 1.0)):
+    image = np.ascontiguousarray(image, np.float32)
+    certainty = np.ascontiguousarray(certainty, np.float32)
+    out = np.empty_like(image)
+    d = _dims(image.shape, spacing)
+    _chk(lib().ife_or_normalized_gaussian_convolution(
+        _p(image, C.c_float), _p(certainty, C.c_float), _p(out, C.c_float), C.byref(d),
+        C.c_double(sigma)), "normconv")
+    return out
+
+
+def derivative(vol, order, direction_xyz, spacing=(1.0, 1.0, 1.0), dscale=DSCALE_ITK):
+    vol = np.ascontiguousarray(vol, np.float32)
+    out = np.empty_like(vol)
+    d = _dims(vol.shape, spacing)
+    _chk(lib().ife_or_derivative(_p(vol, C.c_float), _p(out, C.c_float), C.byref(d),
+                                 C.c_int(order), C.c_int(direction_xyz), C.c_int(dscale)),
+         "derivative")
+    return out
+
+
+def hessian3d(vol, spacing=(1.0, 1.0, 1.0), dscale=DSCALE_ITK):
+    vol = np.ascontiguousarray(vol, np.float32)
+    out = np.empty(vol.shape + (6,), np.float32)
+    d = _dims(vol.shape, spacing)
+    _chk(lib().ife_or_hessian3d(_p(vol, C.c_float), _p(out, C.c_float), C.byref(d),
+                                C.c_int(dscale)), "hessian3d")
+    return out
+
+
+def gradient_magnitude(vol, spacing=(1.0, 1.0, 1.0)):
+    vol = np.ascontiguousarray(vol, np.float32)
+    out = np.empty_like(vol)
+    d = _dims(vol.shape, spacing)
+    _chk(lib().ife_or_gradient_magnitude(_p(vol, C.c_float), _p(out, C.c_float), C.byref(d)),
+         "gradmag")
+    return out
+
+
+def emphysema_features(image, mask, sigma, spacing=(1.0, 1.0, 1.0), trig_mode=TRIG_CMATH,
+                       dscale=DSCALE_ITK):
+    image = np.ascontiguousarray(image, np.float32)
+    mask = np.ascontiguousarray(mask, np.uint8)
+    out = np.empty(image.shape + (8,), np.float32)
+    d = _dims(image.shape, spacing)
+    _chk(lib().ife_or_emphysema_features(
+        _p(image, C.c_float), _p(mask, C.c_uint8), _p(out, C.c_float), C.byref(d),
+        C.c_double(sigma), C.c_int(trig_mode), C.c_int(dscale)), "emphysema_features")
+    return out
+
+
+def fd_hessian_features(image, mask, spacing=(1.0, 1.0, 1.0), trig_mode=TRIG_CMATH,
+                        dscale=DSCALE_ITK):
+    image = np.ascontiguousarray(image, np.float32)
+    out = np.empty(image.shape + (6,), np.float32)
+    d = _dims(image.shape, spacing)
+    if mask is None:
+        mp = None
+    else:
+        mask = np.ascontiguousarray(mask, np.uint8)
+        mp = _p(mask, C.c_uint8)
+    _chk(lib().ife_or_fd_hessian_features(_p(image, C.c_float), mp, _p(out, C.c_float),
+                                          C.byref(d), C.c_int(trig_mode), C.c_int(dscale)),
+         "fd_hessian_features")
+    return out
+
+
+def fd_gradient_features(image, mask_f32, spacing=(1.0, 1.0, 1.0)):
+    image = np.ascontiguousarray(image, np.float32)
+    mask_f32 = np.ascontiguousarray(mask_f32, np.float32)
+    out = np.empty_like(image)
+    d = _dims(image.shape, spacing)
+    _chk(lib().ife_or_fd_gradient_features(_p(image, C.c_float), _p(mask_f32, C.c_float),
+                                           _p(out, C.c_float), C.byref(d)), "fd_gradient")
+    return out
+
+
+def mask_image_f64(image, mask, outside=0.0):
+    image = np.ascontiguousarray(image, np.float64)
+    mask = np.ascontiguousarray(mask, np.float64)
+    out = np.empty_like(image)
+    lib().ife_or_mask_image_f64(_p(image, C.c_double), _p(mask, C.c_double), C.c_double(outside),
+                                _p(out, C.c_double), C.c_int64(image.size))
+    return out
