@@ -1,0 +1,739 @@
+// ife_capi.hip -- C-ABI (include/ife_hip.h) over the HIP kernels.  gfx950 only.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+// (-ffp-contract=off is part of the numerical contract, see iir_kernels.hpp).
+#include "../../include/ife_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "feature_kernels.hpp"
+#include "iir_kernels.hpp"
+
+using namespace ife;
+
+namespace {
+
+enum KernelKind {
+  KK_IIR_Z = 0,
+  KK_IIR_X,
+  KK_IIR_Y,
+  KK_FEATURES,
+  KK_EIG_BATCH,
+  KK_DIVIDE,
+  KK_MASK,
+  KK_COUNT
+};
+const char *kKindNames[KK_COUNT] = {"iir_z", "iir_x", "iir_y", "features",
+                                    "eig_batch", "divide", "mask_f64"};
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+struct ProfRec {
+  int kind;
+  hipEvent_t a, b;
+};
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct ife_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int trig_mode = 0;
+  int dscale_mode = 0;
+  int profile = 0;
+  int zchunk = 64;
+  int iir_block = 16;
+  DevBuf fld[4];  // num ping/pong, den ping/pong
+  DevBuf ck_y, ck_x;
+  DevBuf st_img, st_mask, st_aux, st_out;  // HOST-mode staging
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> ev_pool;
+  double acc_ms[KK_COUNT] = {0};
+  int64_t acc_n[KK_COUNT] = {0};
+};
+
+namespace {
+
+int fail(ife_ctx *ctx, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  else g_create_error = buf;
+  return code;
+}
+
+#define IFE_HIP(ctx, call)                                                                  \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? IFE_E_NOMEM : IFE_E_HIP, "%s: %s", #call, \
+                  hipGetErrorString(e_));                                                   \
+  } while (0)
+
+int ensure(ife_ctx *ctx, DevBuf &b, size_t bytes) {
+  if (b.cap >= bytes) return IFE_OK;
+  if (b.p) {
+    IFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IFE_HIP(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  IFE_HIP(ctx, hipMalloc(&b.p, bytes));
+  b.cap = bytes;
+  return IFE_OK;
+}
+
+int check_vol(ife_ctx *ctx, const ife_volume_desc *v, bool need_iir) {
+  if (!v) return fail(ctx, IFE_E_ARG, "volume descriptor is null");
+  if (v->nx <= 0 || v->ny <= 0 || v->nz <= 0)
+    return fail(ctx, IFE_E_SIZE, "volume size must be positive (got %lld x %lld x %lld)",
+                (long long)v->nx, (long long)v->ny, (long long)v->nz);
+  if (v->nx > 0x7fffffff || v->ny > 0x7fffffff || v->nz > 0x7fffffff)
+    return fail(ctx, IFE_E_SIZE, "axis length exceeds 2^31-1");
+  if (!(v->sx > 0.0) || !(v->sy > 0.0) || !(v->sz > 0.0))
+    return fail(ctx, IFE_E_ARG, "spacing must be positive");
+  if (need_iir && (v->nx < 4 || v->ny < 4 || v->nz < 4))
+    return fail(ctx, IFE_E_SIZE,
+                "the recursive Gaussian needs at least 4 voxels along every axis "
+                "(got %lld x %lld x %lld)",
+                (long long)v->nx, (long long)v->ny, (long long)v->nz);
+  return IFE_OK;
+}
+
+// ---- profiling -------------------------------------------------------------------
+struct ProfScope {
+  ife_ctx *ctx;
+  ProfRec rec;
+  bool on;
+  ProfScope(ife_ctx *c, int kind) : ctx(c), on(c->profile != 0) {
+    if (!on) return;
+    rec.kind = kind;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!ctx->ev_pool.empty()) {
+        e = ctx->ev_pool.back();
+        ctx->ev_pool.pop_back();
+      } else if (hipEventCreate(&e) != hipSuccess) {
+        e = nullptr;
+      }
+      return e;
+    };
+    rec.a = get();
+    rec.b = get();
+    if (!rec.a || !rec.b) { on = false; return; }
+    (void)hipEventRecord(rec.a, ctx->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(rec.b, ctx->stream);
+    ctx->prof.push_back(rec);
+  }
+};
+
+int drain_profile(ife_ctx *ctx) {
+  if (ctx->prof.empty()) return IFE_OK;
+  IFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto &r : ctx->prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      ctx->acc_ms[r.kind] += ms;
+      ctx->acc_n[r.kind] += 1;
+    }
+    ctx->ev_pool.push_back(r.a);
+    ctx->ev_pool.push_back(r.b);
+  }
+  ctx->prof.clear();
+  return IFE_OK;
+}
+
+// ---- recursive Gaussian coefficients ------------------------------------------------
+// [ITK-upstream] itk::RecursiveGaussianImageFilter::SetUp, ZeroOrder,
+// NormalizeAcrossScale off.  Host-side, double.
+int gauss_coeffs(double sigma, double spacing, IirCoef *c) {
+  const double A1 = 1.3530, B1 = 1.8151, W1 = 0.6681, L1 = -1.3932;
+  const double A2 = -0.3531, B2 = 0.0902, W2 = 2.0787, L2 = -1.3732;
+  if (spacing < 0.0) spacing = -spacing;
+  if (spacing < 1e-8) return -1;
+  const double sd = sigma / spacing;
+  const double Sin1 = std::sin(W1 / sd), Sin2 = std::sin(W2 / sd);
+  const double Cos1 = std::cos(W1 / sd), Cos2 = std::cos(W2 / sd);
+  const double Exp1 = std::exp(L1 / sd), Exp2 = std::exp(L2 / sd);
+  c->D4 = Exp1 * Exp1 * Exp2 * Exp2;
+  c->D3 = -2 * Cos1 * Exp1 * Exp2 * Exp2;
+  c->D3 += -2 * Cos2 * Exp2 * Exp1 * Exp1;
+  c->D2 = 4 * Cos2 * Cos1 * Exp1 * Exp2;
+  c->D2 += Exp1 * Exp1 + Exp2 * Exp2;
+  c->D1 = -2 * (Exp2 * Cos2 + Exp1 * Cos1);
+  const double SD = 1.0 + c->D1 + c->D2 + c->D3 + c->D4;
+  c->N0 = A1 + A2;
+  c->N1 = Exp2 * (B2 * Sin2 - (A2 + 2 * A1) * Cos2);
+  c->N1 += Exp1 * (B1 * Sin1 - (A1 + 2 * A2) * Cos1);
+  c->N2 = (A1 + A2) * Cos2 * Cos1;
+  c->N2 -= B1 * Cos2 * Sin1 + B2 * Cos1 * Sin2;
+  c->N2 *= 2 * Exp1 * Exp2;
+  c->N2 += A2 * Exp1 * Exp1 + A1 * Exp2 * Exp2;
+  c->N3 = Exp2 * Exp1 * Exp1 * (B2 * Sin2 - A2 * Cos2);
+  c->N3 += Exp1 * Exp2 * Exp2 * (B1 * Sin1 - A1 * Cos1);
+  const double SN = c->N0 + c->N1 + c->N2 + c->N3;
+  const double alpha0 = 2 * SN / SD - c->N0;
+  const double nrm = 1.0 / alpha0;
+  c->N0 *= nrm; c->N1 *= nrm; c->N2 *= nrm; c->N3 *= nrm;
+  c->M1 = c->N1 - c->D1 * c->N0;
+  c->M2 = c->N2 - c->D2 * c->N0;
+  c->M3 = c->N3 - c->D3 * c->N0;
+  c->M4 = -c->D4 * c->N0;
+  const double SN2 = c->N0 + c->N1 + c->N2 + c->N3;
+  const double SM2 = c->M1 + c->M2 + c->M3 + c->M4;
+  const double SD2 = 1.0 + c->D1 + c->D2 + c->D3 + c->D4;
+  c->BN1 = c->D1 * SN2 / SD2; c->BN2 = c->D2 * SN2 / SD2;
+  c->BN3 = c->D3 * SN2 / SD2; c->BN4 = c->D4 * SN2 / SD2;
+  c->BM1 = c->D1 * SM2 / SD2; c->BM2 = c->D2 * SM2 / SD2;
+  c->BM3 = c->D3 * SM2 / SD2; c->BM4 = c->D4 * SM2 / SD2;
+  return 0;
+}
+
+// [ITK-upstream] DerivativeOperator coefficients after FlipAxes + ScaleCoefficients:
+// order 1 -> {-0.5, 0, 0.5} * s ; order 2 -> {1, -2, 1} * s  (s = 1/spacing, or
+// 1/spacing^2 for order 2 with IFE_OPT_DSCALE_MODE=1).
+DerivCoef deriv_coeffs(const ife_volume_desc *v, int dscale_mode) {
+  DerivCoef d;
+  const double sp[3] = {v->sx, v->sy, v->sz};
+  for (int a = 0; a < 3; ++a) {
+    const double s1 = 1.0 / sp[a];
+    const double s2 = dscale_mode == 1 ? s1 * s1 : s1;
+    d.m1[a] = -0.5 * s1;
+    d.p1[a] = 0.5 * s1;
+    d.a2[a] = 1.0 * s2;
+    d.b2[a] = -2.0 * s2;
+    d.c2[a] = 1.0 * s2;
+  }
+  return d;
+}
+
+IirGeom geom_for_axis(const ife_volume_desc *v, int axis) {
+  IirGeom g;
+  const int64_t nx = v->nx, ny = v->ny, nz = v->nz;
+  if (axis == 2) {
+    g.n = nz; g.nlines = nx * ny; g.sstride = nx * ny; g.inner = nx * ny; g.outer = 0;
+  } else if (axis == 1) {
+    g.n = ny; g.nlines = nx * nz; g.sstride = nx; g.inner = nx; g.outer = nx * ny;
+  } else {
+    g.n = nx; g.nlines = ny * nz; g.sstride = 1; g.inner = 1; g.outer = nx;
+  }
+  return g;
+}
+
+size_t ck_blocks(int64_t n, int K) { return (size_t)((n + K - 1) / K); }
+
+int ensure_ck(ife_ctx *ctx, const ife_volume_desc *v) {
+  const int K = ctx->iir_block;
+  size_t need_y = 0, need_x = 0;
+  for (int a = 0; a < 3; ++a) {
+    IirGeom g = geom_for_axis(v, a);
+    const size_t nb = ck_blocks(g.n, K);
+    need_y = std::max(need_y, nb * 4 * (size_t)g.nlines * sizeof(double));
+    need_x = std::max(need_x, nb * 3 * (size_t)g.nlines * sizeof(float));
+  }
+  int rc = ensure(ctx, ctx->ck_y, need_y);
+  if (rc) return rc;
+  return ensure(ctx, ctx->ck_x, need_x);
+}
+
+template <typename SRC>
+int launch_strided(ife_ctx *ctx, SRC src, float *out, const ife_volume_desc *v, int axis,
+                   const IirCoef &c) {
+  IirGeom g = geom_for_axis(v, axis);
+  Checkpoint ck{(double *)ctx->ck_y.p, (float *)ctx->ck_x.p};
+  const unsigned blocks = (unsigned)((g.nlines + 255) / 256);
+  // 32-bit offsets of the buffer accesses (iir_kernels.hpp "addressing")
+  if ((int64_t)ctx->iir_block * g.sstride * 4 >= (int64_t)1 << 31 ||
+      g.outer * 4 >= (int64_t)1 << 32 || g.nlines * 8 * 3 >= (int64_t)1 << 32)
+    return fail(ctx, IFE_E_SIZE, "volume too large for the 32-bit offsets of the line kernels");
+  ProfScope ps(ctx, axis == 2 ? KK_IIR_Z : KK_IIR_Y);
+  if (ctx->iir_block == 8)
+    hipLaunchKernelGGL((iir_strided_kernel<8, SRC>), dim3(blocks), dim3(256), 0, ctx->stream, src,
+                       out, g, c, ck);
+  else
+    hipLaunchKernelGGL((iir_strided_kernel<16, SRC>), dim3(blocks), dim3(256), 0, ctx->stream,
+                       src, out, g, c, ck);
+  IFE_HIP(ctx, hipGetLastError());
+  return IFE_OK;
+}
+
+int launch_contig(ife_ctx *ctx, const float *in, float *out, const ife_volume_desc *v,
+                  const IirCoef &c) {
+  IirGeom g = geom_for_axis(v, 0);
+  Checkpoint ck{(double *)ctx->ck_y.p, (float *)ctx->ck_x.p};
+  const unsigned blocks = (unsigned)((g.nlines + 255) / 256);
+  if (g.nlines * 8 * 3 >= (int64_t)1 << 32)
+    return fail(ctx, IFE_E_SIZE, "volume too large for the 32-bit offsets of the line kernels");
+  ProfScope ps(ctx, KK_IIR_X);
+  if (ctx->iir_block == 8)
+    hipLaunchKernelGGL((iir_contig_kernel<8>), dim3(blocks), dim3(256), 0, ctx->stream, in, out,
+                       g, c, ck);
+  else
+    hipLaunchKernelGGL((iir_contig_kernel<16>), dim3(blocks), dim3(256), 0, ctx->stream, in, out,
+                       g, c, ck);
+  IFE_HIP(ctx, hipGetLastError());
+  return IFE_OK;
+}
+
+// SmoothingRecursiveGaussianImageFilter: Z pass from `src`, then X, then Y.
+// Result lands in buf_a (buf_b is the intermediate).
+template <typename SRC>
+int smooth_field(ife_ctx *ctx, SRC src, float *buf_a, float *buf_b, const ife_volume_desc *v,
+                 double sigma) {
+  IirCoef cz, cx, cy;
+  if (gauss_coeffs(sigma, v->sz, &cz) || gauss_coeffs(sigma, v->sx, &cx) ||
+      gauss_coeffs(sigma, v->sy, &cy))
+    return fail(ctx, IFE_E_ARG, "spacing is suspiciously small");
+  int rc = launch_strided(ctx, src, buf_a, v, 2, cz);
+  if (!rc) rc = launch_contig(ctx, buf_a, buf_b, v, cx);
+  if (!rc) rc = launch_strided(ctx, SrcF32{buf_b}, buf_a, v, 1, cy);
+  return rc;
+}
+
+template <int MODE, typename VAL, typename TM>
+int launch_features(ife_ctx *ctx, VAL val, const TM *mask, float *out,
+                    const ife_volume_desc *v, int layout) {
+  FeatGeom g;
+  g.nx = (int)v->nx; g.ny = (int)v->ny; g.nz = (int)v->nz;
+  g.zchunk = ctx->zchunk;
+  g.plane = v->nx * v->ny;
+  g.nvox = g.plane * v->nz;
+  const DerivCoef dc = deriv_coeffs(v, ctx->dscale_mode);
+  dim3 grid((unsigned)((v->nx + FT_TX - 1) / FT_TX), (unsigned)((v->ny + FT_TY - 1) / FT_TY),
+            (unsigned)((v->nz + g.zchunk - 1) / g.zchunk));
+  if (grid.y > 65535u || grid.z > 65535u)
+    return fail(ctx, IFE_E_SIZE, "volume too large for the feature kernel grid");
+  ProfScope ps(ctx, KK_FEATURES);
+  hipLaunchKernelGGL((features_kernel<MODE, VAL, TM>), grid, dim3(FT_THREADS), 0, ctx->stream,
+                     val, mask, out, g, dc, layout == IFE_PLANAR ? 1 : 0, ctx->trig_mode);
+  IFE_HIP(ctx, hipGetLastError());
+  return IFE_OK;
+}
+
+size_t dtype_size(int dt) {
+  switch (dt) {
+    case IFE_F32: return 4;
+    case IFE_I16: return 2;
+    case IFE_U8: return 1;
+    case IFE_U16: return 2;
+  }
+  return 0;
+}
+
+int check_layout_mem(ife_ctx *ctx, int layout, int mem) {
+  if (layout != IFE_INTERLEAVED && layout != IFE_PLANAR)
+    return fail(ctx, IFE_E_ARG, "bad layout %d", layout);
+  if (mem != IFE_MEM_HOST && mem != IFE_MEM_DEVICE) return fail(ctx, IFE_E_ARG, "bad mem %d", mem);
+  return IFE_OK;
+}
+
+// Stage a host input on the device (HOST mode) or pass the device pointer through.
+int stage_in(ife_ctx *ctx, int mem, const void *src, size_t bytes, DevBuf &buf, const void **dev) {
+  if (src == nullptr) { *dev = nullptr; return IFE_OK; }
+  if (mem == IFE_MEM_DEVICE) { *dev = src; return IFE_OK; }
+  int rc = ensure(ctx, buf, bytes);
+  if (rc) return rc;
+  IFE_HIP(ctx, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  *dev = buf.p;
+  return IFE_OK;
+}
+
+int stage_out_begin(ife_ctx *ctx, int mem, void *dst, size_t bytes, void **dev) {
+  if (mem == IFE_MEM_DEVICE) { *dev = dst; return IFE_OK; }
+  int rc = ensure(ctx, ctx->st_out, bytes);
+  if (rc) return rc;
+  *dev = ctx->st_out.p;
+  return IFE_OK;
+}
+
+int stage_out_end(ife_ctx *ctx, int mem, void *dst, size_t bytes) {
+  if (mem == IFE_MEM_DEVICE) return IFE_OK;
+  IFE_HIP(ctx, hipMemcpyAsync(dst, ctx->st_out.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  IFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return IFE_OK;
+}
+
+int bind(ife_ctx *ctx) {
+  if (!ctx) return IFE_E_ARG;
+  IFE_HIP(ctx, hipSetDevice(ctx->device));
+  return IFE_OK;
+}
+
+}  // namespace
+
+template <typename TI, typename TM>
+static int emphysema_typed(ife_ctx *ctx, const TI *img, const TM *msk, const ife_volume_desc *vol,
+                           const float *sigmas, int n_sigmas, float *dout, int layout) {
+  const size_t n = (size_t)(vol->nx * vol->ny * vol->nz);
+  float *num = (float *)ctx->fld[0].p, *numb = (float *)ctx->fld[1].p;
+  float *den = (float *)ctx->fld[2].p, *denb = (float *)ctx->fld[3].p;
+  for (int s = 0; s < n_sigmas; ++s) {
+    const double sigma = (double)sigmas[s];
+    int rc;
+    if (msk) {
+      rc = smooth_field(ctx, SrcMul<TI, TM>{img, msk}, num, numb, vol, sigma);
+      if (!rc) rc = smooth_field(ctx, SrcImg<TM>{msk}, den, denb, vol, sigma);
+    } else {
+      // certainty == 1 everywhere: image*1 is the image, and G(1) is exactly 1.0f at
+      // every voxel (DESIGN.md "all-ones certainty"), so A/B == A.
+      rc = smooth_field(ctx, SrcImg<TI>{img}, num, numb, vol, sigma);
+    }
+    if (rc) return rc;
+    rc = launch_features<FEAT_FEATURES8>(ctx, ValSmooth{num, msk ? den : nullptr}, msk,
+                                         dout + (size_t)s * n * IFE_NUM_FEATURES, vol, layout);
+    if (rc) return rc;
+  }
+  return IFE_OK;
+}
+
+
+// =====================================================================================
+extern "C" {
+
+int ife_abi_version(void) { return IFE_ABI_VERSION; }
+
+int ife_ctx_create(int device, ife_ctx **out) {
+  if (!out) return fail(nullptr, IFE_E_ARG, "ctx out pointer is null");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(nullptr, IFE_E_HIP, "no HIP device available (%s); this library has no CPU path",
+                e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  if (device < 0 || device >= count)
+    return fail(nullptr, IFE_E_ARG, "device %d out of range (0..%d)", device, count - 1);
+  hipDeviceProp_t prop;
+  IFE_HIP(nullptr, hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, IFE_E_HIP, "device %d is %s; this library is built for gfx950 only",
+                device, prop.gcnArchName);
+  IFE_HIP(nullptr, hipSetDevice(device));
+  ife_ctx *c = new (std::nothrow) ife_ctx();
+  if (!c) return fail(nullptr, IFE_E_NOMEM, "host allocation failed");
+  c->device = device;
+  *out = c;
+  return IFE_OK;
+}
+
+void ife_ctx_destroy(ife_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  DevBuf *bufs[] = {&ctx->fld[0], &ctx->fld[1], &ctx->fld[2], &ctx->fld[3], &ctx->ck_y,
+                    &ctx->ck_x,   &ctx->st_img, &ctx->st_mask, &ctx->st_aux, &ctx->st_out};
+  for (DevBuf *b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  for (auto &r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+  delete ctx;
+}
+
+const char *ife_last_error(const ife_ctx *ctx) {
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int ife_ctx_set_stream(ife_ctx *ctx, void *hip_stream) {
+  if (!ctx) return IFE_E_ARG;
+  ctx->stream = (hipStream_t)hip_stream;
+  return IFE_OK;
+}
+
+int ife_ctx_set_option(ife_ctx *ctx, int option, int value) {
+  if (!ctx) return IFE_E_ARG;
+  switch (option) {
+    case IFE_OPT_TRIG_MODE:
+      if (value != 0 && value != 1) return fail(ctx, IFE_E_ARG, "trig mode must be 0 or 1");
+      ctx->trig_mode = value;
+      return IFE_OK;
+    case IFE_OPT_DSCALE_MODE:
+      if (value != 0 && value != 1) return fail(ctx, IFE_E_ARG, "dscale mode must be 0 or 1");
+      ctx->dscale_mode = value;
+      return IFE_OK;
+    case IFE_OPT_PROFILE:
+      ctx->profile = value ? 1 : 0;
+      return IFE_OK;
+    case IFE_OPT_ZCHUNK:
+      if (value < 1) return fail(ctx, IFE_E_ARG, "zchunk must be >= 1");
+      ctx->zchunk = value;
+      return IFE_OK;
+    case IFE_OPT_IIR_BLOCK:
+      if (value != 8 && value != 16) return fail(ctx, IFE_E_ARG, "iir block must be 8 or 16");
+      ctx->iir_block = value;
+      return IFE_OK;
+  }
+  return fail(ctx, IFE_E_ARG, "unknown option %d", option);
+}
+
+int ife_ctx_reserve(ife_ctx *ctx, const ife_volume_desc *vol) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  rc = check_vol(ctx, vol, false);
+  if (rc) return rc;
+  const size_t nb = (size_t)(vol->nx * vol->ny * vol->nz) * sizeof(float);
+  for (int i = 0; i < 4 && !rc; ++i) rc = ensure(ctx, ctx->fld[i], nb);
+  if (!rc) rc = ensure_ck(ctx, vol);
+  return rc;
+}
+
+int ife_ctx_synchronize(ife_ctx *ctx) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  IFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return IFE_OK;
+}
+
+// ---- a1 / a2 ------------------------------------------------------------------------
+static int eig_batch(ife_ctx *ctx, const float *A6, int64_t n, float *outv, int mem, int nout) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if (n < 0 || (n > 0 && (!A6 || !outv))) return fail(ctx, IFE_E_ARG, "null pointer");
+  if (mem != IFE_MEM_HOST && mem != IFE_MEM_DEVICE) return fail(ctx, IFE_E_ARG, "bad mem");
+  if (n == 0) return IFE_OK;
+  const void *dA;
+  void *dO;
+  rc = stage_in(ctx, mem, A6, (size_t)n * 6 * 4, ctx->st_img, &dA);
+  if (!rc) rc = stage_out_begin(ctx, mem, outv, (size_t)n * nout * 4, &dO);
+  if (rc) return rc;
+  {
+    ProfScope ps(ctx, KK_EIG_BATCH);
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (nout == 3)
+      hipLaunchKernelGGL((eig_batch_kernel<3>), dim3(blocks), dim3(256), 0, ctx->stream,
+                         (const float *)dA, (float *)dO, n, ctx->trig_mode);
+    else
+      hipLaunchKernelGGL((eig_batch_kernel<6>), dim3(blocks), dim3(256), 0, ctx->stream,
+                         (const float *)dA, (float *)dO, n, ctx->trig_mode);
+    IFE_HIP(ctx, hipGetLastError());
+  }
+  return stage_out_end(ctx, mem, outv, (size_t)n * nout * 4);
+}
+
+int ife_eigenvalues(ife_ctx *ctx, const float *A6, int64_t n, float *ev3, int mem) {
+  return eig_batch(ctx, A6, n, ev3, mem, 3);
+}
+int ife_eigenvalue_features(ife_ctx *ctx, const float *A6, int64_t n, float *f6, int mem) {
+  return eig_batch(ctx, A6, n, f6, mem, 6);
+}
+
+// ---- a3 -----------------------------------------------------------------------------
+int ife_hessian3d(ife_ctx *ctx, const float *image, const ife_volume_desc *vol, float *out6,
+                  int layout, int mem) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_vol(ctx, vol, false))) return rc;
+  if ((rc = check_layout_mem(ctx, layout, mem))) return rc;
+  if (!image || !out6) return fail(ctx, IFE_E_ARG, "null pointer");
+  const size_t n = (size_t)(vol->nx * vol->ny * vol->nz);
+  const void *dI;
+  void *dO;
+  if ((rc = stage_in(ctx, mem, image, n * 4, ctx->st_img, &dI))) return rc;
+  if ((rc = stage_out_begin(ctx, mem, out6, n * 24, &dO))) return rc;
+  rc = launch_features<FEAT_HESSIAN6>(ctx, ValRaw<float>{(const float *)dI},
+                                      (const uint8_t *)nullptr, (float *)dO, vol, layout);
+  if (rc) return rc;
+  return stage_out_end(ctx, mem, out6, n * 24);
+}
+
+int ife_gradient_magnitude(ife_ctx *ctx, const float *image, const ife_volume_desc *vol,
+                           float *out, int mem) {
+  return ife_fd_gradient_features(ctx, image, nullptr, vol, out, mem);
+}
+
+// ---- a4 -----------------------------------------------------------------------------
+int ife_normalized_gaussian_convolution(ife_ctx *ctx, const float *image,
+                                        const float *certainty, const ife_volume_desc *vol,
+                                        float sigma, float *out, int mem) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_vol(ctx, vol, true))) return rc;
+  if (mem != IFE_MEM_HOST && mem != IFE_MEM_DEVICE) return fail(ctx, IFE_E_ARG, "bad mem");
+  if (!image || !certainty || !out) return fail(ctx, IFE_E_ARG, "null pointer");
+  if (!(sigma > 0.0f)) return fail(ctx, IFE_E_ARG, "sigma must be positive");
+  if ((rc = ife_ctx_reserve(ctx, vol))) return rc;
+  const size_t n = (size_t)(vol->nx * vol->ny * vol->nz);
+  const void *dI, *dC;
+  void *dO;
+  if ((rc = stage_in(ctx, mem, image, n * 4, ctx->st_img, &dI))) return rc;
+  if ((rc = stage_in(ctx, mem, certainty, n * 4, ctx->st_aux, &dC))) return rc;
+  if ((rc = stage_out_begin(ctx, mem, out, n * 4, &dO))) return rc;
+  float *num = (float *)ctx->fld[0].p, *numb = (float *)ctx->fld[1].p;
+  float *den = (float *)ctx->fld[2].p, *denb = (float *)ctx->fld[3].p;
+  rc = smooth_field(ctx, SrcMulF{(const float *)dI, (const float *)dC}, num, numb, vol, sigma);
+  if (!rc) rc = smooth_field(ctx, SrcF32{(const float *)dC}, den, denb, vol, sigma);
+  if (rc) return rc;
+  {
+    ProfScope ps(ctx, KK_DIVIDE);
+    hipLaunchKernelGGL(divide_kernel, dim3(2048), dim3(256), 0, ctx->stream, num, den,
+                       (float *)dO, (int64_t)n);
+    IFE_HIP(ctx, hipGetLastError());
+  }
+  return stage_out_end(ctx, mem, out, n * 4);
+}
+
+// ---- a5 + a9 ------------------------------------------------------------------------
+int ife_emphysema_features(ife_ctx *ctx, const void *image, int image_dtype, const void *mask,
+                           int mask_dtype, const ife_volume_desc *vol, const float *sigmas,
+                           int n_sigmas, float *out, int layout, int mem) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_vol(ctx, vol, true))) return rc;
+  if ((rc = check_layout_mem(ctx, layout, mem))) return rc;
+  if (!image || !out || !sigmas) return fail(ctx, IFE_E_ARG, "null pointer");
+  if (n_sigmas < 1) return fail(ctx, IFE_E_ARG, "at least one sigma is required");
+  for (int s = 0; s < n_sigmas; ++s)
+    if (!(sigmas[s] > 0.0f)) return fail(ctx, IFE_E_ARG, "sigma[%d] must be positive", s);
+  if (image_dtype != IFE_F32 && image_dtype != IFE_I16)
+    return fail(ctx, IFE_E_ARG, "image dtype must be IFE_F32 or IFE_I16");
+  if (mask && mask_dtype != IFE_U8 && mask_dtype != IFE_U16)
+    return fail(ctx, IFE_E_ARG, "mask dtype must be IFE_U8 or IFE_U16");
+  if ((rc = ife_ctx_reserve(ctx, vol))) return rc;
+  const size_t n = (size_t)(vol->nx * vol->ny * vol->nz);
+  const size_t out_bytes = n * IFE_NUM_FEATURES * 4 * (size_t)n_sigmas;
+  const void *dI, *dM;
+  void *dO;
+  if ((rc = stage_in(ctx, mem, image, n * dtype_size(image_dtype), ctx->st_img, &dI))) return rc;
+  if ((rc = stage_in(ctx, mem, mask, n * (mask ? dtype_size(mask_dtype) : 0), ctx->st_mask, &dM)))
+    return rc;
+  if ((rc = stage_out_begin(ctx, mem, out, out_bytes, &dO))) return rc;
+  float *dout = (float *)dO;
+  const bool u16 = mask && mask_dtype == IFE_U16;
+  if (image_dtype == IFE_F32) {
+    rc = u16 ? emphysema_typed(ctx, (const float *)dI, (const uint16_t *)dM, vol, sigmas, n_sigmas,
+                               dout, layout)
+             : emphysema_typed(ctx, (const float *)dI, (const uint8_t *)dM, vol, sigmas, n_sigmas,
+                               dout, layout);
+  } else {
+    rc = u16 ? emphysema_typed(ctx, (const int16_t *)dI, (const uint16_t *)dM, vol, sigmas,
+                               n_sigmas, dout, layout)
+             : emphysema_typed(ctx, (const int16_t *)dI, (const uint8_t *)dM, vol, sigmas,
+                               n_sigmas, dout, layout);
+  }
+  if (rc) return rc;
+  return stage_out_end(ctx, mem, out, out_bytes);
+}
+
+// ---- a6 -----------------------------------------------------------------------------
+int ife_fd_hessian_features(ife_ctx *ctx, const void *image, int image_dtype, const void *mask,
+                            int mask_dtype, const ife_volume_desc *vol, float *out6, int layout,
+                            int mem) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_vol(ctx, vol, false))) return rc;
+  if ((rc = check_layout_mem(ctx, layout, mem))) return rc;
+  if (!image || !out6) return fail(ctx, IFE_E_ARG, "null pointer");
+  if (image_dtype != IFE_F32 && image_dtype != IFE_I16)
+    return fail(ctx, IFE_E_ARG, "image dtype must be IFE_F32 or IFE_I16");
+  if (mask && mask_dtype != IFE_U8 && mask_dtype != IFE_U16)
+    return fail(ctx, IFE_E_ARG, "mask dtype must be IFE_U8 or IFE_U16");
+  const size_t n = (size_t)(vol->nx * vol->ny * vol->nz);
+  const void *dI, *dM;
+  void *dO;
+  if ((rc = stage_in(ctx, mem, image, n * dtype_size(image_dtype), ctx->st_img, &dI))) return rc;
+  if ((rc = stage_in(ctx, mem, mask, n * (mask ? dtype_size(mask_dtype) : 0), ctx->st_mask, &dM)))
+    return rc;
+  if ((rc = stage_out_begin(ctx, mem, out6, n * 24, &dO))) return rc;
+  const bool u16 = mask && mask_dtype == IFE_U16;
+  if (image_dtype == IFE_F32) {
+    rc = u16 ? launch_features<FEAT_EIG6>(ctx, ValRaw<float>{(const float *)dI},
+                                          (const uint16_t *)dM, (float *)dO, vol, layout)
+             : launch_features<FEAT_EIG6>(ctx, ValRaw<float>{(const float *)dI},
+                                          (const uint8_t *)dM, (float *)dO, vol, layout);
+  } else {
+    rc = u16 ? launch_features<FEAT_EIG6>(ctx, ValRaw<int16_t>{(const int16_t *)dI},
+                                          (const uint16_t *)dM, (float *)dO, vol, layout)
+             : launch_features<FEAT_EIG6>(ctx, ValRaw<int16_t>{(const int16_t *)dI},
+                                          (const uint8_t *)dM, (float *)dO, vol, layout);
+  }
+  if (rc) return rc;
+  return stage_out_end(ctx, mem, out6, n * 24);
+}
+
+// ---- a7 -----------------------------------------------------------------------------
+int ife_fd_gradient_features(ife_ctx *ctx, const float *image, const float *mask,
+                             const ife_volume_desc *vol, float *out, int mem) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_vol(ctx, vol, false))) return rc;
+  if (mem != IFE_MEM_HOST && mem != IFE_MEM_DEVICE) return fail(ctx, IFE_E_ARG, "bad mem");
+  if (!image || !out) return fail(ctx, IFE_E_ARG, "null pointer");
+  const size_t n = (size_t)(vol->nx * vol->ny * vol->nz);
+  const void *dI, *dM;
+  void *dO;
+  if ((rc = stage_in(ctx, mem, image, n * 4, ctx->st_img, &dI))) return rc;
+  if ((rc = stage_in(ctx, mem, mask, mask ? n * 4 : 0, ctx->st_aux, &dM))) return rc;
+  if ((rc = stage_out_begin(ctx, mem, out, n * 4, &dO))) return rc;
+  rc = launch_features<FEAT_GRADMAG>(ctx, ValRaw<float>{(const float *)dI}, (const float *)dM,
+                                     (float *)dO, vol, IFE_PLANAR);
+  if (rc) return rc;
+  return stage_out_end(ctx, mem, out, n * 4);
+}
+
+// ---- a8 -----------------------------------------------------------------------------
+int ife_mask_image_f64(ife_ctx *ctx, const double *image, const double *mask, double outside,
+                       int64_t n, double *out, int mem) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if (n < 0 || (n > 0 && (!image || !mask || !out))) return fail(ctx, IFE_E_ARG, "null pointer");
+  if (mem != IFE_MEM_HOST && mem != IFE_MEM_DEVICE) return fail(ctx, IFE_E_ARG, "bad mem");
+  if (n == 0) return IFE_OK;
+  const void *dI, *dM;
+  void *dO;
+  if ((rc = stage_in(ctx, mem, image, (size_t)n * 8, ctx->st_img, &dI))) return rc;
+  if ((rc = stage_in(ctx, mem, mask, (size_t)n * 8, ctx->st_aux, &dM))) return rc;
+  if ((rc = stage_out_begin(ctx, mem, out, (size_t)n * 8, &dO))) return rc;
+  {
+    ProfScope ps(ctx, KK_MASK);
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(mask_f64_kernel, dim3(blocks), dim3(256), 0, ctx->stream,
+                       (const double *)dI, (const double *)dM, outside, (double *)dO, n);
+    IFE_HIP(ctx, hipGetLastError());
+  }
+  return stage_out_end(ctx, mem, out, (size_t)n * 8);
+}
+
+// ---- measurement ----------------------------------------------------------------------
+int ife_get_kernel_times(ife_ctx *ctx, ife_kernel_time *entries, int max_entries) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if ((rc = drain_profile(ctx))) return rc;
+  int k = 0;
+  for (int i = 0; i < KK_COUNT && k < max_entries; ++i) {
+    if (ctx->acc_n[i] == 0) continue;
+    memset(&entries[k], 0, sizeof entries[k]);
+    strncpy(entries[k].name, kKindNames[i], sizeof entries[k].name - 1);
+    entries[k].launches = ctx->acc_n[i];
+    entries[k].total_ms = ctx->acc_ms[i];
+    ++k;
+  }
+  return k;
+}
+
+int ife_reset_kernel_times(ife_ctx *ctx) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if ((rc = drain_profile(ctx))) return rc;
+  for (int i = 0; i < KK_COUNT; ++i) { ctx->acc_ms[i] = 0; ctx->acc_n[i] = 0; }
+  return IFE_OK;
+}
+
+}  // extern "C"

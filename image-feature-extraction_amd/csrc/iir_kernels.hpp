@@ -1,0 +1,518 @@
+// iir_kernels.hpp -- ITK's 4th-order recursive (Deriche) Gaussian as line kernels.
+//
+// Restates, per line, itk::RecursiveSeparableImageFilter::FilterDataArray with the
+// ZeroOrder coefficients of itk::RecursiveGaussianImageFilter, which the reference
+// reaches through NormalizedGaussianConvolutionImageFilter.hxx:51-55
+// (SmoothingRecursiveGaussianImageFilter: axis order Z, X, Y; float images between
+// axes; double line state).  SURVEY.md section 8 row a4.
+//
+// Mapping to the machine: one line per lane, 64 adjacent lines per wave.  A line is
+// walked in register blocks of K samples.
+//   forward sweep : causal recursion; at every block start the state
+//                   (y[i-1..i-4] as double, x[i-1..i-3] as float) is written to a
+//                   checkpoint array (44 B per line per K samples).
+//   backward sweep: per block, reload the checkpoint, recompute the K causal values
+//                   into registers, run the anticausal recursion over the same K
+//                   samples, and store float(causal + anticausal).
+// This keeps the exact sequential double arithmetic of the reference (every
+// multiply and add rounds separately: the TU is built with -ffp-contract=off) while
+// the only extra HBM traffic is the checkpoint array.  The causal partial sums never
+// leave registers.
+//
+// Axis variants:
+//   strided (Z, Y): lanes own adjacent x, samples are `sstride` elements apart;
+//                   every load/store of a wave is one contiguous 256-B row.
+//   contig (X)    : lines are contiguous in memory; a wave stages 64 lines x K
+//                   samples through LDS (16-B global accesses, transposed so that a
+//                   lane again owns one line).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ife {
+
+struct IirCoef {
+  double N0, N1, N2, N3;
+  double D1, D2, D3, D4;
+  double M1, M2, M3, M4;
+  double BN1, BN2, BN3, BN4;
+  double BM1, BM2, BM3, BM4;
+};
+
+struct IirGeom {
+  int64_t n;        // samples per line
+  int64_t nlines;   // number of lines
+  int64_t sstride;  // element stride between consecutive samples of a line
+  int64_t inner;    // strided: lines per contiguous row (line L -> base (L%inner)+(L/inner)*outer)
+  int64_t outer;    // strided: element stride between rows of lines; contig: line pitch
+};
+
+struct CausalState {
+  double x1, x2, x3;      // x[i-1], x[i-2], x[i-3]
+  double y1, y2, y3, y4;  // y[i-1..i-4]
+};
+struct AntiState {
+  double x1, x2, x3, x4;  // x[i+1..i+4]
+  double y1, y2, y3, y4;  // y[i+1..i+4]
+};
+
+// scratch[i] = data[i]*N0 + data[i-1]*N1 + data[i-2]*N2 + data[i-3]*N3
+// scratch[i] -= scratch[i-1]*D1 + scratch[i-2]*D2 + scratch[i-3]*D3 + scratch[i-4]*D4
+__device__ __forceinline__ double causal_step(CausalState &s, double xin, const IirCoef &c) {
+  const double a = xin * c.N0 + s.x1 * c.N1 + s.x2 * c.N2 + s.x3 * c.N3;
+  const double t = s.y1 * c.D1 + s.y2 * c.D2 + s.y3 * c.D3 + s.y4 * c.D4;
+  const double y = a - t;
+  s.x3 = s.x2; s.x2 = s.x1; s.x1 = xin;
+  s.y4 = s.y3; s.y3 = s.y2; s.y2 = s.y1; s.y1 = y;
+  return y;
+}
+// Border form: for i < 4 the taps that reach before the line use outV1*BN_k, which is
+// what the state holds (y_k initialised to outV1) times the boundary coefficient.
+__device__ __forceinline__ double causal_step_edge(CausalState &s, double xin, const IirCoef &c,
+                                                   int64_t i) {
+  const double d1 = i < 1 ? c.BN1 : c.D1;
+  const double d2 = i < 2 ? c.BN2 : c.D2;
+  const double d3 = i < 3 ? c.BN3 : c.D3;
+  const double d4 = i < 4 ? c.BN4 : c.D4;
+  const double a = xin * c.N0 + s.x1 * c.N1 + s.x2 * c.N2 + s.x3 * c.N3;
+  const double t = s.y1 * d1 + s.y2 * d2 + s.y3 * d3 + s.y4 * d4;
+  const double y = a - t;
+  s.x3 = s.x2; s.x2 = s.x1; s.x1 = xin;
+  s.y4 = s.y3; s.y3 = s.y2; s.y2 = s.y1; s.y1 = y;
+  return y;
+}
+// scratch[i] = data[i+1]*M1 + data[i+2]*M2 + data[i+3]*M3 + data[i+4]*M4
+// scratch[i] -= scratch[i+1]*D1 + scratch[i+2]*D2 + scratch[i+3]*D3 + scratch[i+4]*D4
+__device__ __forceinline__ double anti_step(AntiState &s, double xin, const IirCoef &c) {
+  const double a = s.x1 * c.M1 + s.x2 * c.M2 + s.x3 * c.M3 + s.x4 * c.M4;
+  const double t = s.y1 * c.D1 + s.y2 * c.D2 + s.y3 * c.D3 + s.y4 * c.D4;
+  const double y = a - t;
+  s.x4 = s.x3; s.x3 = s.x2; s.x2 = s.x1; s.x1 = xin;
+  s.y4 = s.y3; s.y3 = s.y2; s.y2 = s.y1; s.y1 = y;
+  return y;
+}
+__device__ __forceinline__ double anti_step_edge(AntiState &s, double xin, const IirCoef &c,
+                                                 int64_t i, int64_t n) {
+  const double d1 = i + 1 >= n ? c.BM1 : c.D1;
+  const double d2 = i + 2 >= n ? c.BM2 : c.D2;
+  const double d3 = i + 3 >= n ? c.BM3 : c.D3;
+  const double d4 = i + 4 >= n ? c.BM4 : c.D4;
+  const double a = s.x1 * c.M1 + s.x2 * c.M2 + s.x3 * c.M3 + s.x4 * c.M4;
+  const double t = s.y1 * d1 + s.y2 * d2 + s.y3 * d3 + s.y4 * d4;
+  const double y = a - t;
+  s.x4 = s.x3; s.x3 = s.x2; s.x2 = s.x1; s.x1 = xin;
+  s.y4 = s.y3; s.y3 = s.y2; s.y2 = s.y1; s.y1 = y;
+  return y;
+}
+
+// ---- addressing ------------------------------------------------------------------
+// Every global access below is a raw buffer access: a wave-uniform 128-bit resource
+// (base pointer rebuilt per register block from scalars), a constant 32-bit per-lane
+// byte offset, and a scalar per-sample offset.  The per-sample address arithmetic is
+// scalar, no 64-bit address lives in VGPRs, and SGPR pressure stays at one resource
+// per stream (the 20 double coefficients already take 40 SGPRs).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ rsrc_t make_rsrc(const void *ubase) {
+  // stride 0, no range limit: offsets are validated on the host (ife_capi.hip)
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ubase), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld_f32(rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st_f32(rsrc_t r, uint32_t voff, uint32_t soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, 0);
+}
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double buf_ld_f64(rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st_f64(rsrc_t r, uint32_t voff, uint32_t soff, double v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+}
+template <typename T>
+__device__ __forceinline__ float buf_ld_as_f32(rsrc_t r, uint32_t voff, uint32_t soff);
+template <>
+__device__ __forceinline__ float buf_ld_as_f32<float>(rsrc_t r, uint32_t voff, uint32_t soff) {
+  return buf_ld_f32(r, voff, soff);
+}
+template <>
+__device__ __forceinline__ float buf_ld_as_f32<uint8_t>(rsrc_t r, uint32_t voff, uint32_t soff) {
+  return (float)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0);
+}
+template <>
+__device__ __forceinline__ float buf_ld_as_f32<uint16_t>(rsrc_t r, uint32_t voff, uint32_t soff) {
+  return (float)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+}
+template <>
+__device__ __forceinline__ float buf_ld_as_f32<int16_t>(rsrc_t r, uint32_t voff, uint32_t soff) {
+  return (float)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+}
+
+// ---- sample sources ------------------------------------------------------------
+// at(u): resources based at uniform element index u;  ld(B, v, s): element at per-lane
+// element offset v plus scalar element offset s from that base.
+// SrcF32: a float volume (X and Y passes, certainty given as float)
+// SrcMul<TI,TM>: image*certainty with certainty = float(mask)
+//   (MultiplyImageFilter, NormalizedGaussianConvolutionImageFilter.hxx:48-49, after
+//    CastImageFilter, ImageToEmphysemaFeaturesFilter.hxx:21,110)
+// SrcImg<T>: float(volume of T) (the certainty itself, or the image when it is all ones)
+template <typename TI>
+struct SrcImg {
+  const TI *img;
+  struct At { rsrc_t a; };
+  __device__ __forceinline__ At at(int64_t u) const { return At{make_rsrc(img + u)}; }
+  __device__ __forceinline__ float ld(const At &b, uint32_t v, uint32_t s) const {
+    return buf_ld_as_f32<TI>(b.a, v * (uint32_t)sizeof(TI), s * (uint32_t)sizeof(TI));
+  }
+};
+using SrcF32 = SrcImg<float>;
+template <typename TI, typename TM>
+struct SrcMul {
+  const TI *img;
+  const TM *msk;
+  struct At { rsrc_t a, m; };
+  __device__ __forceinline__ At at(int64_t u) const {
+    return At{make_rsrc(img + u), make_rsrc(msk + u)};
+  }
+  __device__ __forceinline__ float ld(const At &b, uint32_t v, uint32_t s) const {
+    return buf_ld_as_f32<TI>(b.a, v * (uint32_t)sizeof(TI), s * (uint32_t)sizeof(TI)) *
+           buf_ld_as_f32<TM>(b.m, v * (uint32_t)sizeof(TM), s * (uint32_t)sizeof(TM));
+  }
+};
+using SrcMulF = SrcMul<float, float>;
+
+struct Checkpoint {
+  double *y;  // [nblocks][4][nlines]
+  float *x;   // [nblocks][3][nlines]
+};
+
+__device__ __forceinline__ void ck_store(const Checkpoint &ck, int64_t b, int64_t nl, int64_t Lw,
+                                         uint32_t lane, const CausalState &s) {
+  const rsrc_t ry = make_rsrc(ck.y + (b * 4) * nl + Lw);
+  const rsrc_t rx = make_rsrc(ck.x + (b * 3) * nl + Lw);
+  const uint32_t sy = (uint32_t)nl * 8u, sx = (uint32_t)nl * 4u;
+  buf_st_f64(ry, lane * 8u, 0u, s.y1);
+  buf_st_f64(ry, lane * 8u, sy, s.y2);
+  buf_st_f64(ry, lane * 8u, 2u * sy, s.y3);
+  buf_st_f64(ry, lane * 8u, 3u * sy, s.y4);
+  buf_st_f32(rx, lane * 4u, 0u, (float)s.x1);
+  buf_st_f32(rx, lane * 4u, sx, (float)s.x2);
+  buf_st_f32(rx, lane * 4u, 2u * sx, (float)s.x3);
+}
+__device__ __forceinline__ void ck_load(const Checkpoint &ck, int64_t b, int64_t nl, int64_t Lw,
+                                        uint32_t lane, CausalState &s) {
+  const rsrc_t ry = make_rsrc(ck.y + (b * 4) * nl + Lw);
+  const rsrc_t rx = make_rsrc(ck.x + (b * 3) * nl + Lw);
+  const uint32_t sy = (uint32_t)nl * 8u, sx = (uint32_t)nl * 4u;
+  s.y1 = buf_ld_f64(ry, lane * 8u, 0u);
+  s.y2 = buf_ld_f64(ry, lane * 8u, sy);
+  s.y3 = buf_ld_f64(ry, lane * 8u, 2u * sy);
+  s.y4 = buf_ld_f64(ry, lane * 8u, 3u * sy);
+  s.x1 = (double)buf_ld_f32(rx, lane * 4u, 0u);
+  s.x2 = (double)buf_ld_f32(rx, lane * 4u, sx);
+  s.x3 = (double)buf_ld_f32(rx, lane * 4u, 2u * sx);
+}
+
+// One register block of the backward sweep: recompute the K causal values from the
+// block's start state, run the anticausal recursion over the same samples and leave
+// float(causal + anticausal) in xb.  `edge` blocks (the first one and those within 4
+// samples of the line end) take the border forms and skip samples >= n.
+template <int K>
+__device__ __forceinline__ void backward_block(float (&xb)[K], CausalState &s, AntiState &a,
+                                               const IirCoef &c, int64_t i0, int64_t n,
+                                               bool edge) {
+  double cz[K];
+  if (!edge) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) cz[j] = causal_step(s, (double)xb[j], c);
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) {
+      const double y = anti_step(a, (double)xb[j], c);
+      xb[j] = (float)(cz[j] + y);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      if (i0 + j < n) cz[j] = causal_step_edge(s, (double)xb[j], c, i0 + j);
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) {
+      if (i0 + j < n) {
+        const double y = anti_step_edge(a, (double)xb[j], c, i0 + j, n);
+        xb[j] = (float)(cz[j] + y);
+      }
+    }
+  }
+}
+
+// =================================================================================
+// strided axes (Z and Y)
+// =================================================================================
+template <int K, typename SRC>
+__global__ __launch_bounds__(256) void iir_strided_kernel(SRC src, float *__restrict__ out,
+                                                          IirGeom g, IirCoef c, Checkpoint ck) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const int64_t Lw =
+      uniform64((int64_t)blockIdx.x * blockDim.x + (int64_t)(threadIdx.x & ~63u));
+  if (Lw >= g.nlines) return;  // wave-uniform
+  const int64_t n = g.n, st = g.sstride, nl = g.nlines;
+  int64_t L = Lw + lane;
+  const bool live = L < nl;
+  if (!live) L = nl - 1;  // compute on a valid line, never store
+  const int64_t base = (L % g.inner) + (L / g.inner) * g.outer;
+  const int64_t wbase = uniform64(base);          // lane 0 of the wave
+  const uint32_t voff = (uint32_t)(base - wbase);  // elements (one row jump at most)
+  const uint32_t sst = (uint32_t)st;               // K*st*4 < 2^31 is checked on the host
+  const int64_t nb = (n + K - 1) / K;
+
+  float xb[K], xn[K];
+
+  // ---------------- forward sweep: checkpoints only ----------------
+  {
+    CausalState s;
+    if (nb > 1) {
+      const auto B = src.at(wbase);
+#pragma unroll
+      for (int j = 0; j < K; ++j) xb[j] = src.ld(B, voff, (uint32_t)j * sst);
+    }
+    for (int64_t b = 0; b + 1 < nb; ++b) {
+      const int64_t i0 = b * K;
+      if (b + 2 < nb) {  // prefetch the next full block
+        const auto B = src.at(wbase + (i0 + K) * st);
+#pragma unroll
+        for (int j = 0; j < K; ++j) xn[j] = src.ld(B, voff, (uint32_t)j * sst);
+      }
+      if (b > 0) {
+        if (live) ck_store(ck, b, nl, Lw, lane, s);
+#pragma unroll
+        for (int j = 0; j < K; ++j) causal_step(s, (double)xb[j], c);
+      } else {
+        const double x0 = (double)xb[0];
+        s.x1 = s.x2 = s.x3 = x0;
+        s.y1 = s.y2 = s.y3 = s.y4 = x0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) causal_step_edge(s, (double)xb[j], c, j);
+      }
+#pragma unroll
+      for (int j = 0; j < K; ++j) xb[j] = xn[j];
+    }
+    if (nb > 1 && live) ck_store(ck, nb - 1, nl, Lw, lane, s);
+  }
+
+  // ---------------- backward sweep ----------------
+  {
+    AntiState a;
+    {
+      const int64_t i0 = (nb - 1) * K;
+      const auto B = src.at(wbase + i0 * st);
+      const uint32_t last = (uint32_t)(n - 1 - i0);  // 0..K-1
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+        xb[j] = src.ld(B, voff, ((uint32_t)j < last ? (uint32_t)j : last) * sst);
+      // x[n-1]: the clamped loads make every slot >= last hold it
+      const double xN = (double)xb[K - 1];
+      a.x1 = a.x2 = a.x3 = a.x4 = xN;
+      a.y1 = a.y2 = a.y3 = a.y4 = xN;
+    }
+    for (int64_t b = nb - 1; b >= 0; --b) {
+      const int64_t i0 = b * K;
+      if (b > 0) {
+        const auto B = src.at(wbase + (i0 - K) * st);
+#pragma unroll
+        for (int j = 0; j < K; ++j) xn[j] = src.ld(B, voff, (uint32_t)j * sst);
+      }
+      CausalState s;
+      if (b > 0) {
+        ck_load(ck, b, nl, Lw, live ? lane : 0u, s);
+      } else {
+        const double x0 = (double)xb[0];
+        s.x1 = s.x2 = s.x3 = x0;
+        s.y1 = s.y2 = s.y3 = s.y4 = x0;
+      }
+      const bool edge = (b == 0) || (i0 + K + 4 > n);
+      backward_block<K>(xb, s, a, c, i0, n, edge);
+      if (live) {
+        const rsrc_t ro = make_rsrc(out + wbase + i0 * st);
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+          if (!edge || i0 + j < n) buf_st_f32(ro, voff * 4u, (uint32_t)j * sst * 4u, xb[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < K; ++j) xb[j] = xn[j];
+    }
+  }
+}
+
+// =================================================================================
+// contiguous axis (X): 64 lines x K samples staged through LDS per wave
+// =================================================================================
+template <int K>
+struct XTile {
+  static constexpr int PITCH = K + 4;  // floats; keeps rows 16-B aligned, conflict-free b128 reads
+  static constexpr int FLOATS = 64 * PITCH;
+};
+
+// A wave's DS instructions execute in order, so a tile written and then read by the
+// same wave needs no barrier: only the compiler must be kept from moving LDS
+// accesses across this point (the "memory" clobber), and global traffic in flight
+// is left alone (no vmcnt wait, unlike a workgroup-scope fence).
+__device__ __forceinline__ void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Load samples [i0, i0+K) of the wave's 64 lines into xb (lane = line).
+// `rows` points at sample 0 of the wave's first line (uniform); pitch is the line pitch.
+template <int K>
+__device__ __forceinline__ void xtile_load(const float *rows, float *tile, uint32_t lane,
+                                           int64_t nrows, int64_t pitch, int64_t i0, int64_t n,
+                                           bool vec_ok, float (&xb)[K]) {
+  constexpr int P = XTile<K>::PITCH;
+  constexpr int V = K / 4;     // float4 per line-block
+  constexpr int LPI = 64 / V;  // lines covered per wave instruction
+  if (vec_ok && i0 + K <= n) {
+    const rsrc_t r4 = make_rsrc(rows + i0);
+    u32x4 v[V];
+#pragma unroll
+    for (int r = 0; r < V; ++r) {
+      uint32_t row = (lane / V) + r * LPI;
+      if ((int64_t)row >= nrows) row = (uint32_t)(nrows - 1);
+      const uint32_t off = (row * (uint32_t)pitch + 4u * (lane % V)) * 4u;
+      v[r] = __builtin_amdgcn_raw_buffer_load_b128(r4, off, 0u, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < V; ++r)
+      *reinterpret_cast<u32x4 *>(tile + ((lane / V) + r * LPI) * P + 4 * (lane % V)) = v[r];
+  } else {
+#pragma unroll
+    for (int e = 0; e < K; ++e) {
+      const uint32_t idx = e * 64 + lane;
+      uint32_t row = idx / K;
+      const uint32_t col = idx % K;
+      const uint32_t trow = row;
+      if ((int64_t)row >= nrows) row = (uint32_t)(nrows - 1);
+      int64_t i = i0 + col;
+      if (i >= n) i = n - 1;
+      tile[trow * P + col] = rows[(int64_t)row * pitch + i];
+    }
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+    const float4 t = *reinterpret_cast<const float4 *>(tile + lane * P + 4 * q);
+    xb[4 * q + 0] = t.x; xb[4 * q + 1] = t.y; xb[4 * q + 2] = t.z; xb[4 * q + 3] = t.w;
+  }
+  wave_lds_sync();
+}
+
+template <int K>
+__device__ __forceinline__ void xtile_store(float *rows, float *tile, uint32_t lane,
+                                            int64_t nrows, int64_t pitch, int64_t i0, int64_t n,
+                                            bool vec_ok, const float (&ob)[K]) {
+  constexpr int P = XTile<K>::PITCH;
+  constexpr int V = K / 4;
+  constexpr int LPI = 64 / V;
+#pragma unroll
+  for (int q = 0; q < V; ++q)
+    *reinterpret_cast<float4 *>(tile + lane * P + 4 * q) =
+        make_float4(ob[4 * q + 0], ob[4 * q + 1], ob[4 * q + 2], ob[4 * q + 3]);
+  wave_lds_sync();
+  if (vec_ok && i0 + K <= n) {
+    const rsrc_t r4 = make_rsrc(rows + i0);
+#pragma unroll
+    for (int r = 0; r < V; ++r) {
+      const uint32_t row = (lane / V) + r * LPI;
+      const u32x4 v = *reinterpret_cast<const u32x4 *>(tile + row * P + 4 * (lane % V));
+      const uint32_t off = (row * (uint32_t)pitch + 4u * (lane % V)) * 4u;
+      if ((int64_t)row < nrows) __builtin_amdgcn_raw_buffer_store_b128(v, r4, off, 0u, 0);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < K; ++e) {
+      const uint32_t idx = e * 64 + lane;
+      const uint32_t row = idx / K, col = idx % K;
+      const int64_t i = i0 + col;
+      if ((int64_t)row < nrows && i < n) rows[(int64_t)row * pitch + i] = tile[row * P + col];
+    }
+  }
+  wave_lds_sync();
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void iir_contig_kernel(const float *__restrict__ in,
+                                                         float *__restrict__ out, IirGeom g,
+                                                         IirCoef c, Checkpoint ck) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * XTile<K>::FLOATS];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float *tile = lds + wave * XTile<K>::FLOATS;
+  const int64_t line0 = uniform64(((int64_t)blockIdx.x * 4 + wave) * 64);
+  if (line0 >= g.nlines) return;
+  const int64_t n = g.n, nl = g.nlines, pitch = g.outer;
+  const int64_t nrows = nl - line0 < 64 ? nl - line0 : 64;  // live lines of this wave
+  const int64_t nb = (n + K - 1) / K;
+  // 16-B accesses need aligned rows; the per-lane byte offset must fit 32 bits
+  const bool vec_ok = (pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
+                      (pitch * 64 * 4 < (int64_t)0x7fffffff);
+  const bool live = (int64_t)lane < nrows;
+  const float *rows_in = in + line0 * pitch;
+  float *rows_out = out + line0 * pitch;
+
+  float xb[K];
+
+  // ---------------- forward sweep ----------------
+  {
+    CausalState s;
+    for (int64_t b = 0; b + 1 < nb; ++b) {
+      const int64_t i0 = b * K;
+      xtile_load<K>(rows_in, tile, lane, nrows, pitch, i0, n, vec_ok, xb);
+      if (b > 0) {
+        if (live) ck_store(ck, b, nl, line0, lane, s);
+#pragma unroll
+        for (int j = 0; j < K; ++j) causal_step(s, (double)xb[j], c);
+      } else {
+        const double x0 = (double)xb[0];
+        s.x1 = s.x2 = s.x3 = x0;
+        s.y1 = s.y2 = s.y3 = s.y4 = x0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) causal_step_edge(s, (double)xb[j], c, j);
+      }
+    }
+    if (nb > 1 && live) ck_store(ck, nb - 1, nl, line0, lane, s);
+  }
+
+  // ---------------- backward sweep ----------------
+  {
+    AntiState a;
+    for (int64_t b = nb - 1; b >= 0; --b) {
+      const int64_t i0 = b * K;
+      xtile_load<K>(rows_in, tile, lane, nrows, pitch, i0, n, vec_ok, xb);
+      if (b == nb - 1) {
+        // x[n-1]: the clamped tile load makes every slot past the line end hold it
+        const double xN = (double)xb[K - 1];
+        a.x1 = a.x2 = a.x3 = a.x4 = xN;
+        a.y1 = a.y2 = a.y3 = a.y4 = xN;
+      }
+      CausalState s;
+      if (b > 0) {
+        ck_load(ck, b, nl, line0, live ? lane : 0u, s);
+      } else {
+        const double x0 = (double)xb[0];
+        s.x1 = s.x2 = s.x3 = x0;
+        s.y1 = s.y2 = s.y3 = s.y4 = x0;
+      }
+      const bool edge = (b == 0) || (i0 + K + 4 > n);
+      backward_block<K>(xb, s, a, c, i0, n, edge);
+      xtile_store<K>(rows_out, tile, lane, nrows, pitch, i0, n, vec_ok, xb);
+    }
+  }
+}
+
+}  // namespace ife

@@ -1,0 +1,189 @@
+/*
+ * ife_hip.h -- C-ABI of the MI355X (gfx950) per-voxel Hessian feature engine.
+ *
+ * This is the drop-in boundary for the hot path of orting/image-feature-extraction:
+ * the reference runs the path as ITK filter objects inside one process
+ * (headers under include/ife/Filters and include/ife/Numerics); here every stage that the
+ * reference exposes as a filter / functor / tool body has one extern "C" entry
+ * point taking plain pointers and sizes.  The C++ host classes under
+ * image-feature-extraction_amd/host/ (same class and method names as the
+ * reference) and the tools forward to these entry points; INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - volumes are x-fastest: index = x + nx*(y + ny*z)  (itk::Image buffer order)
+ *   - vector outputs: IFE_INTERLEAVED [voxel*ncomp + c] (itk::VectorImage order) or
+ *     IFE_PLANAR [c*nvox + voxel]
+ *   - IFE_MEM_HOST: pointers are host memory, the call copies in/out and blocks;
+ *     IFE_MEM_DEVICE: pointers are device (HBM) memory on the context's device, the
+ *     call enqueues on the context's stream and returns without synchronising
+ *   - every call returns 0 or a negative ife_status; ife_last_error() gives text
+ *   - an ife_ctx is single-owner (one host thread at a time); different contexts
+ *     may run concurrently
+ *   - there is no CPU fallback: every entry point fails with IFE_E_HIP when no
+ *     gfx950 device is usable
+ *
+ * All "reference" citations are paths relative to the reference repository root.
+ */
+#ifndef IFE_HIP_H
+#define IFE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IFE_ABI_VERSION 1
+
+typedef struct ife_ctx ife_ctx;
+
+typedef enum {
+  IFE_OK = 0,
+  IFE_E_ARG = -1,    /* null pointer, bad enum, bad sigma/spacing */
+  IFE_E_SIZE = -2,   /* an axis shorter than 4 where the recursive Gaussian runs
+                        (ITK throws for ln < 4), or a non-positive size */
+  IFE_E_HIP = -3,    /* HIP runtime error (text in ife_last_error) */
+  IFE_E_NOMEM = -4,  /* device or host allocation failed */
+  IFE_E_STATE = -5   /* call sequence error (slab API) */
+} ife_status;
+
+typedef enum { IFE_F32 = 0, IFE_I16 = 1, IFE_U8 = 2, IFE_U16 = 3 } ife_dtype;
+typedef enum { IFE_INTERLEAVED = 0, IFE_PLANAR = 1 } ife_layout;
+typedef enum { IFE_MEM_HOST = 0, IFE_MEM_DEVICE = 1 } ife_mem;
+
+/* Options for ife_ctx_set_option */
+typedef enum {
+  /* 0 (default): sqrt/acos/cos of the solver evaluated in double, the binding the
+   * reference gets when only <cmath> is visible; 1: float overloads (<math.h>
+   * visible).  Symmetric3x3EigenvalueSolver.h:88,115,119-120. */
+  IFE_OPT_TRIG_MODE = 1,
+  /* 0 (default): DerivativeImageFilter scales by 1/spacing once whatever the order
+   * (upstream ITK behaviour); 1: 1/spacing^order.  Same for unit spacing. */
+  IFE_OPT_DSCALE_MODE = 2,
+  /* 1: record a hipEvent pair around every kernel launch so that
+   * ife_get_kernel_times can report per-kernel device time.  Default 0. */
+  IFE_OPT_PROFILE = 3,
+  /* planes per workgroup march of the feature kernel (default 64) */
+  IFE_OPT_ZCHUNK = 4,
+  /* samples per register block of the recursive-Gaussian kernels: 8 or 16 */
+  IFE_OPT_IIR_BLOCK = 5
+} ife_option;
+
+typedef struct {
+  int64_t nx, ny, nz; /* size in voxels */
+  double sx, sy, sz;  /* spacing (physical units per voxel), > 0 */
+} ife_volume_desc;
+
+/* number of feature components, ImageToEmphysemaFeaturesFilter.h:62 (numFeatures) */
+#define IFE_NUM_FEATURES 8
+/* component order of ife_emphysema_features, ExtractFeatures.cxx:126-130 */
+#define IFE_FEATURE_NAMES                                                              \
+  {"GaussianBlur", "GradientMagnitude", "Eigenvalue1", "Eigenvalue2", "Eigenvalue3",   \
+   "LaplacianOfGaussian", "GaussianCurvature", "FrobeniusNorm"}
+
+/* ---- context ----------------------------------------------------------------- */
+
+int ife_abi_version(void);
+/* Creates a context on HIP device `device`.  Replaces nothing in the reference
+ * (which has no device); it owns the workspace the ITK mini-pipeline would hold as
+ * intermediate images (ImageToEmphysemaFeaturesFilter.h:74-117). */
+int ife_ctx_create(int device, ife_ctx **ctx);
+void ife_ctx_destroy(ife_ctx *ctx);
+/* Last error text of this context (or of ife_ctx_create when ctx is NULL).
+ * Stands in for itk::ExceptionObject::what() (ExtractFeatures.cxx:145-152). */
+const char *ife_last_error(const ife_ctx *ctx);
+/* Borrow a hipStream_t for all later launches (NULL = the default stream). */
+int ife_ctx_set_stream(ife_ctx *ctx, void *hip_stream);
+int ife_ctx_set_option(ife_ctx *ctx, int option, int value);
+/* Grow the workspace for volumes of this size now (so that later DEVICE-mode calls
+ * allocate nothing). */
+int ife_ctx_reserve(ife_ctx *ctx, const ife_volume_desc *vol);
+/* Block until everything enqueued by this context has finished. */
+int ife_ctx_synchronize(ife_ctx *ctx);
+
+/* ---- a1 / a2: per-voxel numerics ----------------------------------------------- */
+
+/* Symmetric3x3EigenvalueSolver<float>::operator()
+ * (include/ife/Numerics/Symmetric3x3EigenvalueSolver.h:33-132) on n matrices.
+ * A6: n x (xx,xy,xz,yy,yz,zz); ev3: n x 3, |ev0| >= |ev1| >= |ev2|. */
+int ife_eigenvalues(ife_ctx *ctx, const float *A6, int64_t n, float *ev3, int mem);
+/* EigenvalueFeaturesFunctor<float>::operator()
+ * (include/ife/Numerics/EigenvalueFeaturesFunctor.h:20-31): f6 = n x
+ * (ev0, ev1, ev2, sum, product, sqrt(sum of squares)). */
+int ife_eigenvalue_features(ife_ctx *ctx, const float *A6, int64_t n, float *f6, int mem);
+
+/* ---- a3: Hessian3DImageFilter --------------------------------------------------- */
+
+/* itk::Hessian3DImageFilter<Image<float,3>,VectorImage<float,3>>: SetInput + Update
+ * + GetOutput (include/ife/Filters/Hessian3DImageFilter.h:23-28,
+ * Hessian3DImageFilter.hxx:13-60,80-97).  out6: 6 comps xx,xy,xz,yy,yz,zz. */
+int ife_hessian3d(ife_ctx *ctx, const float *image, const ife_volume_desc *vol, float *out6,
+                  int layout, int mem);
+
+/* itk::GradientMagnitudeImageFilter as wired at
+ * ImageToEmphysemaFeaturesFilter.hxx:27-28 / FiniteDifference_GradientFeatures.cxx:104-106 */
+int ife_gradient_magnitude(ife_ctx *ctx, const float *image, const ife_volume_desc *vol,
+                           float *out, int mem);
+
+/* ---- a4: NormalizedGaussianConvolutionImageFilter ------------------------------- */
+
+/* SetInputImage + SetInputCertainty + SetSigma + Update
+ * (include/ife/Filters/NormalizedGaussianConvolutionImageFilter.h:86-93,
+ * NormalizedGaussianConvolutionImageFilter.hxx:40-63):
+ * out = G_sigma(image*certainty) / G_sigma(certainty), G = ITK recursive Gaussian
+ * run Z, X, Y; zero denominator -> FLT_MAX.  Every axis must be >= 4 voxels. */
+int ife_normalized_gaussian_convolution(ife_ctx *ctx, const float *image,
+                                        const float *certainty, const ife_volume_desc *vol,
+                                        float sigma, float *out, int mem);
+
+/* ---- a5 + a9: ImageToEmphysemaFeaturesFilter, one execution per scale ------------ */
+
+/* SetInputImage + SetInputMask + for each sigma {SetSigma; Update; GetOutput}
+ * (include/ife/Filters/ImageToEmphysemaFeaturesFilter.h:44-62,
+ * ImageToEmphysemaFeaturesFilter.hxx:15-55,99-121; scale loop
+ * tools/ExtractFeatures.cxx:132-154).
+ * image: IFE_F32 or IFE_I16 (converted exactly to float on load);
+ * mask: IFE_U8 or IFE_U16, value used as certainty weight and tested != 0 for the
+ * final masking; NULL means all ones.
+ * out: n_sigmas consecutive 8-component volumes (scale-major), each in `layout`. */
+int ife_emphysema_features(ife_ctx *ctx, const void *image, int image_dtype, const void *mask,
+                           int mask_dtype, const ife_volume_desc *vol, const float *sigmas,
+                           int n_sigmas, float *out, int layout, int mem);
+
+/* ---- a6 / a7 / a8: tool bodies ---------------------------------------------------- */
+
+/* Body of tools/FiniteDifference_HessianFeatures.cxx:126-229 (un-smoothed Hessian,
+ * eigen features, mask==0 -> six zeros), with Hessian3DImageFilter.hxx:34-37 as the
+ * normative derivative wiring (the tool's :155 direction slip is not reproduced).
+ * out6 comps: eig1, eig2, eig3, LoG, Curvature, Frobenius.  mask may be NULL. */
+int ife_fd_hessian_features(ife_ctx *ctx, const void *image, int image_dtype,
+                            const void *mask, int mask_dtype, const ife_volume_desc *vol,
+                            float *out6, int layout, int mem);
+/* Body of tools/FiniteDifference_GradientFeatures.cxx:104-113: the mask is a float
+ * image there. */
+int ife_fd_gradient_features(ife_ctx *ctx, const float *image, const float *mask,
+                             const ife_volume_desc *vol, float *out, int mem);
+/* Body of tools/MaskedImageFilter.cxx:75-93 (double pixels, -v outside value). */
+int ife_mask_image_f64(ife_ctx *ctx, const double *image, const double *mask, double outside,
+                       int64_t n, double *out, int mem);
+
+/* ---- measurement ------------------------------------------------------------------- */
+
+#define IFE_MAX_KERNEL_KINDS 16
+typedef struct {
+  char name[48];
+  int64_t launches;
+  double total_ms; /* sum of hipEvent elapsed times */
+} ife_kernel_time;
+/* With IFE_OPT_PROFILE=1: per-kernel-kind device time accumulated since the last
+ * ife_reset_kernel_times.  Synchronises the stream.  Returns the number of entries
+ * written (<= max_entries) or a negative status. */
+int ife_get_kernel_times(ife_ctx *ctx, ife_kernel_time *entries, int max_entries);
+int ife_reset_kernel_times(ife_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IFE_HIP_H */

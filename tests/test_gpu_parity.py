@@ -1,0 +1,301 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle on
+the same seeded inputs.
+
+Tolerances
+  * everything up to and including the Hessian is IEEE add/mul/div/sqrt on identical
+    operands in identical order (both sides built with -ffp-contract=off), so the bar
+    is BIT-EXACT (compared as floats, i.e. -0.0 == +0.0).
+  * eigenvalues / derived scalars: north_star bar is 1e-5 relative; measured against
+    max(|lambda_1|, tiny) per voxel because the trigonometric solver's error is absolute
+    in ||A||.  With IFE_OPT_TRIG_MODE=0 the device evaluates acos/cos in double like
+    the oracle, so in practice these agree to <= 1 float ulp; the test asserts 1e-6
+    (ten times tighter than the bar) and reports the exact-match fraction.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REL_TOL = 1e-6  # asserted; north_star allows 1e-5
+
+
+def eig_rel_err(got, ref):
+    """max |got-ref| / max(|ref lambda_1|, tiny) over voxels; arrays (..., >=3)."""
+    scale = np.maximum(np.abs(ref[..., 0:1]).astype(np.float64), 1e-30)
+    return float((np.abs(got.astype(np.float64) - ref.astype(np.float64)) / scale).max())
+
+
+def assert_features_close(got, ref, mask=None):
+    """got/ref: (..., 8) [S, G, e1, e2, e3, LoG, prod, frob] or (..., 6) eigen features."""
+    nc = got.shape[-1]
+    assert got.shape == ref.shape
+    assert np.isfinite(got).all() == np.isfinite(ref).all()
+    e0 = nc - 6
+    if nc == 8:
+        np.testing.assert_array_equal(got[..., 0], ref[..., 0])  # smoothed value
+        np.testing.assert_array_equal(got[..., 1], ref[..., 1])  # gradient magnitude
+    g, r = got[..., e0:], ref[..., e0:]
+    lam = np.maximum(np.abs(r[..., 0]).astype(np.float64), 1e-30)
+    d = np.abs(g.astype(np.float64) - r.astype(np.float64))
+    assert (d[..., 0:4] / lam[..., None]).max() <= REL_TOL      # e1, e2, e3, LoG
+    assert (d[..., 4] / lam ** 3).max() <= 3 * REL_TOL          # product
+    assert (d[..., 5] / lam).max() <= REL_TOL                   # Frobenius
+    if mask is not None:
+        assert (got[mask == 0] == 0).all()
+
+
+# ---------------------------------------------------------------------------------
+# a1 / a2
+# ---------------------------------------------------------------------------------
+def _eigen_cases(rng):
+    kat = json.load(open(os.path.join(HERE, "golden", "eigen_kat.json")))["cases"]
+    mats = [c["A"] for c in kat]
+    # diagonal branch: all orderings, magnitude ties, sign ties, zeros
+    for d in ([3, 2, 1], [1, 3, 2], [2, 1, 3], [1, 2, 3], [3, 1, 2], [2, 3, 1], [1, 1, 1],
+              [1, -1, 0], [-1, 1, 0], [2, 2, 1], [1, 2, 2], [2, 1, 2], [0, 0, 0], [-2, 2, -2],
+              [0, 0, 5], [5, 0, 0], [0, -5, 0]):
+        mats.append([d[0], 0, 0, d[1], 0, d[2]])
+    # two equal eigenvalues (r = +-1 clamps), near-degenerate
+    mats += [[2, 1, 1, 2, 1, 2], [-2, 1, 1, -2, 1, -2], [1, 1e-4, 0, 1, 0, 1], [1, 0, 0, 1, 1e-7, 1],
+             [5, 0, 0, 5, 0, -1], [1, 1, 0, 1, 0, 3]]
+    mats = np.array(mats, np.float32)
+    rnd = []
+    for dec in range(-6, 7, 2):
+        rnd.append((rng.standard_normal((600, 6)) * 10.0 ** dec).astype(np.float32))
+    # tiny off-diagonals that underflow p to 0 in float
+    t = rng.standard_normal((200, 6)).astype(np.float32)
+    t[:, [1, 2, 4]] *= np.float32(1e-30)
+    rnd.append(t)
+    return np.concatenate([mats] + rnd, 0)
+
+
+@pytest.mark.parametrize("trig", [0, 1])
+def test_eigen_batch_matches_oracle(ctx, ife, oracle, trig):
+    A = _eigen_cases(np.random.default_rng(7))
+    ctx.set_option(ife.OPT_TRIG_MODE, trig)
+    try:
+        ev = ctx.eigenvalues(A)
+        ft = ctx.eigenvalue_features(A)
+    finally:
+        ctx.set_option(ife.OPT_TRIG_MODE, 0)
+    ev_ref = oracle.eig3(A, trig)
+    ft_ref = oracle.eigfeat(A, trig)
+    assert eig_rel_err(ev, ev_ref) <= REL_TOL
+    assert_features_close(ft, ft_ref)
+    # ordering contract: |e0| >= |e1| >= |e2|
+    a = np.abs(ev)
+    assert (a[:, 0] >= a[:, 1]).all() and (a[:, 1] >= a[:, 2]).all()
+    # the diagonal branch is pure selection: bit exact
+    diag = (A[:, 1] == 0) & (A[:, 2] == 0) & (A[:, 4] == 0)
+    np.testing.assert_array_equal(ev[diag], ev_ref[diag])
+    exact = float((ev == ev_ref).mean())
+    print("trig=%d eigenvalues bit-identical fraction: %.6f" % (trig, exact))
+    if trig == 0:
+        assert exact > 0.999
+
+
+def test_eigen_kat_on_device(ctx):
+    """The reference's own known answers, through the float solver on the GPU."""
+    kat = json.load(open(os.path.join(HERE, "golden", "eigen_kat.json")))["cases"]
+    A = np.array([c["A"] for c in kat], np.float32)
+    ev = ctx.eigenvalues(A)
+    for c, got in zip(kat, ev):
+        exp = np.array(c["expected"], np.float64)
+        tol = 2e-6 * max(1.0, np.abs(exp).max())  # float32 solver vs double expectations
+        assert np.abs(got - exp).max() <= tol, (c["name"], got, exp)
+
+
+def test_eigen_nan_propagates(ctx):
+    A = np.array([[np.nan, 1, 0, 1, 0, 1], [1, np.nan, 0, 1, 0, 1]], np.float32)
+    ev = ctx.eigenvalues(A)
+    assert np.isnan(ev[1]).all()
+    assert np.isnan(ev[0]).any()
+
+
+# ---------------------------------------------------------------------------------
+# a4: recursive Gaussian / normalized convolution  (bit exact)
+# ---------------------------------------------------------------------------------
+SHAPES = [(33, 36, 40), (4, 4, 4), (5, 70, 9), (17, 8, 129), (64, 64, 64)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("sigma,spacing", [(1.0, (1, 1, 1)), (2.5, (0.7, 0.8, 1.25)),
+                                           (0.6, (1, 1, 1))])
+def test_normalized_convolution_bit_exact(ctx, oracle, synth, shape, sigma, spacing):
+    img = synth.volume_f32(shape, 1234)
+    cert = (synth.mask_ellipsoids(shape) > 0).astype(np.float32)
+    cert[0, 0, 0] = 1.0
+    cert += np.float32(0.25) * (np.arange(cert.size).reshape(shape) % 3 == 0)  # fractional weights
+    got = ctx.normalized_gaussian_convolution(img, cert, sigma, spacing)
+    ref = oracle.normalized_gaussian_convolution(img, cert, sigma, spacing)
+    np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("block", [8, 16])
+def test_iir_block_size_is_invisible(ctx, ife, oracle, synth, block):
+    shape = (37, 41, 45)
+    img = synth.volume_f32(shape, 99)
+    cert = np.ones(shape, np.float32)
+    ctx.set_option(ife.OPT_IIR_BLOCK, block)
+    try:
+        got = ctx.normalized_gaussian_convolution(img, cert, 3.0)
+    finally:
+        ctx.set_option(ife.OPT_IIR_BLOCK, 16)
+    np.testing.assert_array_equal(got, oracle.normalized_gaussian_convolution(img, cert, 3.0))
+
+
+def test_zero_certainty_gives_flt_max(ctx, oracle):
+    shape = (12, 12, 12)
+    img = np.ones(shape, np.float32)
+    cert = np.zeros(shape, np.float32)
+    got = ctx.normalized_gaussian_convolution(img, cert, 1.0)
+    assert (got == np.finfo(np.float32).max).all()
+    np.testing.assert_array_equal(got, oracle.normalized_gaussian_convolution(img, cert, 1.0))
+
+
+# ---------------------------------------------------------------------------------
+# a3 / gradient magnitude (bit exact)
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(9, 10, 70), (33, 36, 40), (1, 5, 7), (3, 1, 130), (70, 9, 3)])
+@pytest.mark.parametrize("spacing", [(1, 1, 1), (0.7, 0.8, 1.25)])
+def test_hessian3d_and_gradient_bit_exact(ctx, ife, oracle, synth, shape, spacing):
+    img = synth.volume_f32(shape, 5)
+    h = ctx.hessian3d(img, spacing)
+    np.testing.assert_array_equal(h, oracle.hessian3d(img, spacing))
+    hp = ctx.hessian3d(img, spacing, layout=ife.PLANAR)
+    np.testing.assert_array_equal(np.moveaxis(hp, 0, -1), h)
+    g = ctx.gradient_magnitude(img, spacing)
+    np.testing.assert_array_equal(g, oracle.gradient_magnitude(img, spacing))
+
+
+def test_hessian_spacing_power_option(ctx, ife, oracle, synth):
+    shape = (12, 13, 14)
+    img = synth.volume_f32(shape, 6)
+    sp = (0.5, 2.0, 1.5)
+    ctx.set_option(ife.OPT_DSCALE_MODE, 1)
+    try:
+        h = ctx.hessian3d(img, sp)
+    finally:
+        ctx.set_option(ife.OPT_DSCALE_MODE, 0)
+    np.testing.assert_array_equal(h, oracle.hessian3d(img, sp, dscale=oracle.DSCALE_POW))
+
+
+# ---------------------------------------------------------------------------------
+# a5: the full per-scale feature vector
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,sigmas,spacing", [
+    ((33, 36, 40), [1.0, 2.0], (1, 1, 1)),
+    ((64, 64, 64), [1.0, 2.0, 4.0], (1, 1, 1)),
+    ((20, 70, 130), [1.5], (0.7, 0.7, 1.0)),
+    ((4, 4, 4), [1.0], (1, 1, 1)),
+])
+def test_emphysema_features_match_oracle(ctx, ife, oracle, synth, shape, sigmas, spacing):
+    img = synth.volume_f32(shape, synth.SEED_CONFIG[3])
+    mask = np.minimum(synth.mask_ellipsoids(shape), 1).astype(np.uint8)  # clamp as the tools do
+    mask[0, 0, :] = 1
+    got = ctx.emphysema_features(img, mask, sigmas, spacing)
+    assert got.shape == (len(sigmas),) + shape + (8,)
+    for s, sigma in enumerate(sigmas):
+        ref = oracle.emphysema_features(img, mask, sigma, spacing)
+        assert_features_close(got[s], ref, mask)
+        print("sigma %.1f: all-8-components bit-identical fraction %.6f"
+              % (sigma, float((got[s] == ref).mean())))
+    planar = ctx.emphysema_features(img, mask, sigmas, spacing, layout=ife.PLANAR)
+    np.testing.assert_array_equal(np.moveaxis(planar, 1, -1), got)
+
+
+def test_emphysema_int16_image_u16_mask_labels(ctx, oracle, synth):
+    """int16 CT-like input and an unclamped label mask (0/1/2): the mask VALUE is the
+    certainty weight (ImageToEmphysemaFeaturesFilter.hxx:25), zero test for masking."""
+    shape = (30, 34, 38)
+    img = synth.volume_i16(shape, synth.SEED_CONFIG[5])
+    labels = synth.mask_ellipsoids(shape)
+    got = ctx.emphysema_features(img, labels.astype(np.uint16), [1.5], (0.7, 0.7, 1.0))[0]
+    ref = oracle.emphysema_features(img.astype(np.float32), labels, 1.5, (0.7, 0.7, 1.0))
+    assert_features_close(got, ref, labels)
+
+
+def test_emphysema_null_mask_equals_ones_mask(ctx, synth):
+    shape = (24, 28, 32)
+    img = synth.volume_f32(shape, 11)
+    a = ctx.emphysema_features(img, None, [2.0])
+    b = ctx.emphysema_features(img, np.ones(shape, np.uint8), [2.0])
+    np.testing.assert_array_equal(a, b)
+
+
+def test_emphysema_chunking_is_invisible(ctx, ife, synth):
+    shape = (50, 20, 70)
+    img = synth.volume_f32(shape, 12)
+    mask = np.minimum(synth.mask_ellipsoids(shape), 1).astype(np.uint8)
+    base = ctx.emphysema_features(img, mask, [1.0])
+    for zc in (1, 7, 50, 1000):
+        ctx.set_option(ife.OPT_ZCHUNK, zc)
+        try:
+            np.testing.assert_array_equal(ctx.emphysema_features(img, mask, [1.0]), base)
+        finally:
+            ctx.set_option(ife.OPT_ZCHUNK, 64)
+
+
+# ---------------------------------------------------------------------------------
+# a6 / a7 / a8 tool bodies
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(64, 64, 64), (21, 9, 67)])
+def test_fd_hessian_features(ctx, ife, oracle, synth, shape):
+    img = synth.volume_f32(shape, synth.SEED_CONFIG[1])
+    mask = np.minimum(synth.mask_ellipsoids(shape), 1).astype(np.uint8)
+    got = ctx.fd_hessian_features(img, mask)
+    ref = oracle.fd_hessian_features(img, mask)
+    assert_features_close(got, ref, mask)
+    got_nomask = ctx.fd_hessian_features(img, None)
+    assert_features_close(got_nomask, oracle.fd_hessian_features(img, None))
+    pl = ctx.fd_hessian_features(img, mask, layout=ife.PLANAR)
+    np.testing.assert_array_equal(np.moveaxis(pl, 0, -1), got)
+    i16 = synth.volume_i16(shape, 3)
+    assert_features_close(ctx.fd_hessian_features(i16, mask),
+                          oracle.fd_hessian_features(i16.astype(np.float32), mask), mask)
+
+
+def test_fd_gradient_features(ctx, oracle, synth):
+    shape = (19, 23, 66)
+    img = synth.volume_f32(shape, 8)
+    m = (synth.mask_ellipsoids(shape) > 0).astype(np.float32)
+    np.testing.assert_array_equal(ctx.fd_gradient_features(img, m),
+                                  oracle.fd_gradient_features(img, m))
+
+
+def test_mask_image_f64(ctx, oracle):
+    rng = np.random.default_rng(3)
+    img = rng.standard_normal(100003)
+    m = (rng.random(100003) > 0.5).astype(np.float64) * 2.0
+    np.testing.assert_array_equal(ctx.mask_image_f64(img, m, -7.5), oracle.mask_image_f64(img, m, -7.5))
+
+
+# ---------------------------------------------------------------------------------
+# error behaviour
+# ---------------------------------------------------------------------------------
+def test_short_axis_is_rejected_like_itk(ctx, ife):
+    img = np.zeros((3, 8, 8), np.float32)
+    with pytest.raises(ife.IfeError) as e:
+        ctx.emphysema_features(img, None, [1.0])
+    assert e.value.code == ife.E_SIZE and "at least 4" in str(e.value)
+    with pytest.raises(ife.IfeError) as e:
+        ctx.normalized_gaussian_convolution(img, np.ones_like(img), 1.0)
+    assert e.value.code == ife.E_SIZE
+    # no recursive filter on this path: short axes are fine
+    assert ctx.hessian3d(img).shape == (3, 8, 8, 6)
+
+
+def test_bad_arguments(ctx, ife):
+    img = np.zeros((8, 8, 8), np.float32)
+    with pytest.raises(ife.IfeError) as e:
+        ctx.emphysema_features(img, None, [0.0])
+    assert e.value.code == ife.E_ARG
+    with pytest.raises(ife.IfeError) as e:
+        ctx.emphysema_features(img, None, [1.0], spacing=(0.0, 1, 1))
+    assert e.value.code == ife.E_ARG
+    with pytest.raises(ife.IfeError):
+        ctx.set_option(999, 1)
