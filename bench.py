@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the per-voxel Hessian feature path on MI355X.
+
+Metric (BASELINE.json): "Mvoxels/sec Hessian+eig, 512^3 fp32 3-scale @1/2/4/8 GPU;
+%HBM roofline".  One step = one pass of ImageToEmphysemaFeaturesFilter over the whole
+512^3 float32 synthetic volume at sigma = 1, 2, 4 (BASELINE configs[2] at N=1,
+configs[3] = the same volume cut into N Z-slabs at N>1), 8 output components per
+voxel per scale, inputs resident in HBM when the timed region starts and outputs
+left in HBM.
+
+  value = nx*ny*nz * n_scales / t_step / 1e6          [Mvoxels/s, "voxel-scales"]
+
+Launch: `python bench.py --gpus 1`, or for N>1
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "image-feature-extraction_amd"
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALG_BYTES_PER_VOXEL_SCALE = 37  # 4 (image) + 1 (mask) + 8*4 (out)
+# compulsory bytes per voxel of each kernel kind on its own (DESIGN.md "Kernels")
+KERNEL_ALG_BYTES = {"iir_z": 7.0,   # mean of numerator (4+1 in, 4 out) and denominator (1 in, 4 out)
+                    "iir_x": 8.0, "iir_y": 8.0, "features": 41.0}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, nargs=3, default=[512, 512, 512], metavar=("NZ", "NY", "NX"))
+    ap.add_argument("--sigmas", type=float, nargs="+", default=[1.0, 2.0, 4.0])
+    ap.add_argument("--mask", choices=["ones", "ellipsoids"], default="ones",
+                    help="ones: explicit all-ones uint8 mask (every voxel pays the full path); "
+                         "ellipsoids: ~20%% foreground like a lung mask")
+    ap.add_argument("--layout", choices=["interleaved", "planar"], default="interleaved")
+    ap.add_argument("--trig", type=int, default=0)
+    ap.add_argument("--iir-block", type=int, default=None)
+    ap.add_argument("--zchunk", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=128, help="edge of the CPU baseline cube")
+    return ap.parse_args()
+
+
+def cpu_baseline(synth, seed, sigmas, edge):
+    """The oracle ("port") timed on this host's cores on a bounded sample: an edge^3
+    corner of the same synthetic volume, same sigmas.  Reported, never the target."""
+    from oracle import pyoracle
+    pyoracle.build()
+    threads = min(os.cpu_count() or 1, 16)
+    pyoracle.set_threads(threads)
+    shape = (edge, edge, edge)
+    img = synth.volume_f32(shape, seed)
+    mask = np.ones(shape, np.uint8)
+    pyoracle.emphysema_features(img[:32, :32, :32].copy(), mask[:32, :32, :32].copy(), 1.0)  # warm
+    t0 = time.perf_counter()
+    for s in sigmas:
+        pyoracle.emphysema_features(img, mask, float(s))
+    dt = time.perf_counter() - t0
+    return {"value": round(edge ** 3 * len(sigmas) / dt / 1e6, 3), "unit": "Mvoxels/s",
+            "cores": threads, "kind": "port",
+            "sample": "%d^3 corner of the same synthetic volume, sigmas %s, all-ones mask, "
+                      "%.1f s of CPU work" % (edge, list(sigmas), dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run"
+                         % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = importlib.import_module(PKG)
+    synth = importlib.import_module(PKG + ".synthetic")
+    nz, ny, nx = args.size
+    sigmas = list(args.sigmas)
+    seed = synth.SEED_CONFIG[3]
+    layout = pkg.INTERLEAVED if args.layout == "interleaved" else pkg.PLANAR
+
+    if world > 1:
+        slab = importlib.import_module(PKG + ".slab")
+        runner = slab.SlabRunner(pkg, synth, (nz, ny, nx), sigmas, seed, args.mask, layout,
+                                 rank, world, dev, args)
+    else:
+        runner = SingleGpuRunner(pkg, synth, (nz, ny, nx), sigmas, seed, args.mask, layout, dev,
+                                 args)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        runner.step()
+    runner.ctx.set_option(pkg.OPT_PROFILE, 1)
+    runner.ctx.reset_kernel_times()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    ktimes = runner.ctx.kernel_times()
+    runner.ctx.set_option(pkg.OPT_PROFILE, 0)
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    nvox = nz * ny * nx
+    t_step = dt / args.steps
+    value = nvox * len(sigmas) / t_step / 1e6
+
+    # ---- roofline: whole hot path, per step, from HIP events around every kernel ----
+    kern = {}
+    dev_ms_step = 0.0
+    for name, (n, ms) in ktimes.items():
+        per_step_ms = ms / args.steps
+        dev_ms_step += per_step_ms
+        vox_per_launch = nvox / world
+        avg_ms = ms / n
+        e = {"launches_per_step": n / args.steps, "avg_ms": round(avg_ms, 4),
+             "ms_per_step": round(per_step_ms, 4)}
+        if name in KERNEL_ALG_BYTES:
+            gbs = KERNEL_ALG_BYTES[name] * vox_per_launch / (avg_ms * 1e-3) / 1e9
+            e["alg_bytes_per_voxel"] = KERNEL_ALG_BYTES[name]
+            e["achieved_GBs"] = round(gbs, 1)
+            e["frac"] = round(gbs / HBM_PEAK_GBS, 4)
+        kern[name] = e
+    alg_bytes_step_rank = ALG_BYTES_PER_VOXEL_SCALE * (nvox / world) * len(sigmas)
+    achieved = alg_bytes_step_rank / (dev_ms_step * 1e-3) / 1e9 if dev_ms_step > 0 else 0.0
+    dominant = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "scope": "all kernels of one step (sum of hipEvent durations %.3f ms); "
+                         "algorithmic bytes = 37 B x voxels x scales" % dev_ms_step,
+                "dominant_kernel": dominant, "kernels": kern}
+
+    out = {
+        "metric": "Mvoxels/sec Hessian+eig, 512^3 fp32 3-scale",
+        "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t_step * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32 storage / f64 line recurrences", "data": "synthetic",
+        "config": {"workload": "%dx%dx%d float32 volume, sigma=%s, 8 features/voxel/scale "
+                               "(ImageToEmphysemaFeaturesFilter), uint8 mask=%s, %s output, "
+                               "%s" % (nx, ny, nz, sigmas, args.mask, args.layout,
+                                       "1 GPU" if world == 1 else "%d Z-slabs" % world),
+                   "trig_mode": args.trig},
+        "roofline": roofline,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(synth, seed, sigmas, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+class SingleGpuRunner:
+    def __init__(self, pkg, synth, shape, sigmas, seed, mask_kind, layout, dev, args):
+        import torch
+        self.pkg, self.shape, self.sigmas, self.layout = pkg, shape, sigmas, layout
+        nz, ny, nx = shape
+        img = synth.volume_f32(shape, seed)
+        if mask_kind == "ones":
+            mask = np.ones(shape, np.uint8)
+        else:
+            mask = np.minimum(synth.mask_ellipsoids(shape), 1).astype(np.uint8)
+        self.d_img = torch.from_numpy(img).to(dev)
+        self.d_mask = torch.from_numpy(mask).to(dev)
+        self.d_out = torch.empty((len(sigmas), nz, ny, nx, 8), dtype=torch.float32, device=dev)
+        del img, mask
+        self.ctx = pkg.Context(dev.index or 0)
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.ctx.set_option(pkg.OPT_TRIG_MODE, args.trig)
+        if args.iir_block:
+            self.ctx.set_option(pkg.OPT_IIR_BLOCK, args.iir_block)
+        if args.zchunk:
+            self.ctx.set_option(pkg.OPT_ZCHUNK, args.zchunk)
+        self.ctx.reserve(shape)
+
+    def step(self):
+        self.ctx.emphysema_features_device(
+            self.d_img.data_ptr(), self.pkg.F32, self.d_mask.data_ptr(), self.pkg.U8, self.shape,
+            (1.0, 1.0, 1.0), self.sigmas, self.d_out.data_ptr(), self.layout)
+
+
+if __name__ == "__main__":
+    main()

@@ -84,7 +84,7 @@ def load_library():
     lib.ife_eigenvalue_features.argtypes = [vp, f32p, i64, f32p, i32]
     lib.ife_hessian3d.argtypes = [vp, f32p, vd, f32p, i32, i32]
     lib.ife_gradient_magnitude.argtypes = [vp, f32p, vd, f32p, i32]
-    lib.ife_normalized_gaussian_convolution.argtypes = [vp, f32p, f32p, vd, C.c_float, f32p, i32]
+    lib.ife_normalized_gaussian_convolution.argtypes = [vp, f32p, f32p, vd, C.c_double, f32p, i32]
     lib.ife_emphysema_features.argtypes = [vp, vp, i32, vp, i32, vd, C.POINTER(C.c_float), i32,
                                            f32p, i32, i32]
     lib.ife_fd_hessian_features.argtypes = [vp, vp, i32, vp, i32, vd, f32p, i32, i32]

@@ -7,8 +7,8 @@
 //
 // The translation unit is compiled with -ffp-contract=off, so each float multiply
 // and add below rounds on its own exactly as in a generic x86-64 build of the
-// reference, and float division / sqrt are the correctly rounded forms hipcc emits
-// by default.  The one place the reference's precision depends on its include
+// reference, and float division / sqrtf are the correctly rounded forms hipcc emits
+// by default (NOT __fsqrt_rn, which lowers to the bare 1-ulp v_sqrt_f32).  The one place the reference's precision depends on its include
 // context (unqualified sqrt/acos/cos, :88,:115,:119-120) is the TRIG template
 // parameter: 0 = double functions (only <cmath> visible), 1 = float overloads.
 #pragma once
@@ -48,7 +48,7 @@ __device__ __forceinline__ Eig3 eig3_sym(float A11, float A12, float A13, float 
   p = d1 * d1 + d2 * d2 + d3 * d3 + 2.0f * p;  // :86-87
   // :88  sqrt(p / 6): a correctly rounded double sqrt rounded to float equals the
   // correctly rounded float sqrt (53 >= 2*24+2), so both contexts share this form.
-  p = __fsqrt_rn(p / 6.0f);
+  p = sqrtf(p / 6.0f);
   const float B11 = d1 / p, B12 = A12 / p, B13 = A13 / p;  // :92-97
   const float B22 = d2 / p, B23 = A23 / p, B33 = d3 / p;
   // :98-103, float expression; the "/ 2.0" in double is exact
@@ -88,7 +88,7 @@ __device__ __forceinline__ EigFeat eig_features(float A11, float A12, float A13,
   o.f[2] = ev.e2;
   o.f[3] = ev.e0 + ev.e1 + ev.e2;
   o.f[4] = ev.e0 * ev.e1 * ev.e2;
-  o.f[5] = __fsqrt_rn(ev.e0 * ev.e0 + ev.e1 * ev.e1 + ev.e2 * ev.e2);
+  o.f[5] = sqrtf(ev.e0 * ev.e0 + ev.e1 * ev.e1 + ev.e2 * ev.e2);
   return o;
 }
 

@@ -562,13 +562,13 @@ int ife_gradient_magnitude(ife_ctx *ctx, const float *image, const ife_volume_de
 // ---- a4 -----------------------------------------------------------------------------
 int ife_normalized_gaussian_convolution(ife_ctx *ctx, const float *image,
                                         const float *certainty, const ife_volume_desc *vol,
-                                        float sigma, float *out, int mem) {
+                                        double sigma, float *out, int mem) {
   int rc = bind(ctx);
   if (rc) return rc;
   if ((rc = check_vol(ctx, vol, true))) return rc;
   if (mem != IFE_MEM_HOST && mem != IFE_MEM_DEVICE) return fail(ctx, IFE_E_ARG, "bad mem");
   if (!image || !certainty || !out) return fail(ctx, IFE_E_ARG, "null pointer");
-  if (!(sigma > 0.0f)) return fail(ctx, IFE_E_ARG, "sigma must be positive");
+  if (!(sigma > 0.0)) return fail(ctx, IFE_E_ARG, "sigma must be positive");
   if ((rc = ife_ctx_reserve(ctx, vol))) return rc;
   const size_t n = (size_t)(vol->nx * vol->ny * vol->nz);
   const void *dI, *dC;

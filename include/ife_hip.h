@@ -133,10 +133,13 @@ int ife_gradient_magnitude(ife_ctx *ctx, const float *image, const ife_volume_de
  * (include/ife/Filters/NormalizedGaussianConvolutionImageFilter.h:86-93,
  * NormalizedGaussianConvolutionImageFilter.hxx:40-63):
  * out = G_sigma(image*certainty) / G_sigma(certainty), G = ITK recursive Gaussian
- * run Z, X, Y; zero denominator -> FLT_MAX.  Every axis must be >= 4 voxels. */
+ * run Z, X, Y; zero denominator -> FLT_MAX.  Every axis must be >= 4 voxels.
+ * sigma is double here (ScalarRealType of the Gaussian filter, .h:75,92-93; the
+ * MaskedNormalizedConvolution tool parses doubles, :117) and float in
+ * ife_emphysema_features (ScalarRealType = PixelType there, .h:41,58-59). */
 int ife_normalized_gaussian_convolution(ife_ctx *ctx, const float *image,
                                         const float *certainty, const ife_volume_desc *vol,
-                                        float sigma, float *out, int mem);
+                                        double sigma, float *out, int mem);
 
 /* ---- a5 + a9: ImageToEmphysemaFeaturesFilter, one execution per scale ------------ */
 
