@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, nargs=3, default=[512, 512, 512], metavar=("NZ", "NY", "NX"))
     ap.add_argument("--sigmas", type=float, nargs="+", default=[1.0, 2.0, 4.0])
-    ap.add_argument("--mask", choices=["ones", "ellipsoids"], default="ones",
+    ap.add_argument("--mask", choices=["ones", "ellipsoids", "none"], default="ones",
                     help="ones: explicit all-ones uint8 mask (every voxel pays the full path); "
                          "ellipsoids: ~20%% foreground like a lung mask")
     ap.add_argument("--layout", choices=["interleaved", "planar"], default="interleaved")
@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--iir-block", type=int, default=None)
     ap.add_argument("--zchunk", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=128, help="edge of the CPU baseline cube")
+    ap.add_argument("--cpu-sample", type=int, default=384, help="edge of the CPU baseline cube")
     return ap.parse_args()
 
 
@@ -187,12 +187,13 @@ class SingleGpuRunner:
         self.pkg, self.shape, self.sigmas, self.layout = pkg, shape, sigmas, layout
         nz, ny, nx = shape
         img = synth.volume_f32(shape, seed)
-        if mask_kind == "ones":
-            mask = np.ones(shape, np.uint8)
-        else:
+        if mask_kind == "ellipsoids":
             mask = np.minimum(synth.mask_ellipsoids(shape), 1).astype(np.uint8)
+        else:
+            mask = np.ones(shape, np.uint8)
         self.d_img = torch.from_numpy(img).to(dev)
         self.d_mask = torch.from_numpy(mask).to(dev)
+        self.mask_ptr = None if mask_kind == "none" else self.d_mask.data_ptr()
         self.d_out = torch.empty((len(sigmas), nz, ny, nx, 8), dtype=torch.float32, device=dev)
         del img, mask
         self.ctx = pkg.Context(dev.index or 0)
@@ -206,7 +207,7 @@ class SingleGpuRunner:
 
     def step(self):
         self.ctx.emphysema_features_device(
-            self.d_img.data_ptr(), self.pkg.F32, self.d_mask.data_ptr(), self.pkg.U8, self.shape,
+            self.d_img.data_ptr(), self.pkg.F32, self.mask_ptr, self.pkg.U8, self.shape,
             (1.0, 1.0, 1.0), self.sigmas, self.d_out.data_ptr(), self.layout)
 
 

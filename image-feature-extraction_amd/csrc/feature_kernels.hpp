@@ -104,6 +104,11 @@ __global__ __launch_bounds__(FT_THREADS) void features_kernel(VAL val, const TM 
                                                               float *__restrict__ out, FeatGeom g,
                                                               DerivCoef dc, int planar, int trig) {
   __shared__ float tile[2][FT_HY][FT_HX];
+  // mask tile of the output plane, staged as dwords (per-lane sub-dword global loads are
+  // slow on gfx950); row pitch = 64 mask elements
+  constexpr int MT_DW = FT_TY * FT_TX * (int)sizeof(TM) / 4;  // dwords per plane tile
+  constexpr int MT_DWROW = FT_TX * (int)sizeof(TM) / 4;       // dwords per tile row
+  __shared__ uint32_t mtile[2][MT_DW];
   constexpr int NOUT = FeatNOut<MODE>::value;
   constexpr bool NEED_H = MODE != FEAT_GRADMAG;
   constexpr bool NEED_G = MODE == FEAT_FEATURES8 || MODE == FEAT_GRADMAG;
@@ -136,15 +141,29 @@ __global__ __launch_bounds__(FT_THREADS) void features_kernel(VAL val, const TM 
     r0 = val.ld(pb + off0);
     if (has1) r1 = val.ld(pb + off1);
   }
+  // mask staging: thread t < MT_DW owns dword (t % MT_DWROW) of tile row (t / MT_DWROW).
+  // Vector form needs rows that are dword multiples and a dword-aligned base.
+  const bool mvec = mask != nullptr && ((int64_t)g.nx * (int64_t)sizeof(TM)) % 4 == 0 &&
+                    (reinterpret_cast<uintptr_t>(mask) & 3) == 0;
+  const int mrow = tid / MT_DWROW, mcol = tid % MT_DWROW;
+  const int mx = blockIdx.x * FT_TX + mcol * (4 / (int)sizeof(TM));
+  const int my = blockIdx.y * FT_TY + mrow;
+  const bool mine = mvec && tid < MT_DW && mx < g.nx && my < g.ny;
+  const int64_t moff = (int64_t)mx + (int64_t)g.nx * my;  // element offset inside a plane
+  uint32_t mr = 0;
 
   for (int p = z0 - 1; p <= z1; ++p) {
     const int buf = (p - (z0 - 1)) & 1;
     tile[buf][e0y][e0x] = r0;
     if (has1) tile[buf][e1y][e1x] = r1;
+    if (mine) mtile[buf][tid] = mr;  // mask of plane p-1, loaded one iteration ago
     if (p < z1) {  // issue the next plane's loads before consuming this one
       const int64_t pb = (int64_t)clampi(p + 1, g.nz - 1) * g.plane;
       r0 = val.ld(pb + off0);
       if (has1) r1 = val.ld(pb + off1);
+      // plane p is the output plane of the next iteration
+      if (mine && p >= z0)
+        mr = *reinterpret_cast<const uint32_t *>(mask + (int64_t)p * g.plane + moff);
     }
     __syncthreads();
 
@@ -180,7 +199,10 @@ __global__ __launch_bounds__(FT_THREADS) void features_kernel(VAL val, const TM 
     if (z >= z0 && inb) {
       const int64_t idx = (int64_t)x + (int64_t)g.nx * ((int64_t)y + (int64_t)g.ny * z);
       bool keep = true;
-      if (mask != nullptr) keep = mask[idx] != (TM)0;
+      if (mvec)
+        keep = reinterpret_cast<const TM *>(mtile[buf])[ty * FT_TX + tx] != (TM)0;
+      else if (mask != nullptr)
+        keep = mask[idx] != (TM)0;
       float o[NOUT];
 #pragma unroll
       for (int k = 0; k < NOUT; ++k) o[k] = 0.0f;
@@ -262,6 +284,53 @@ __global__ __launch_bounds__(256) void mask_f64_kernel(const double *__restrict_
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) outv[i] = msk[i] != 0.0 ? img[i] : outside;
+}
+
+// Multiply + Cast prepass: tc = float(image) * float(mask), cf = float(mask)
+// (CastImageFilter ImageToEmphysemaFeaturesFilter.hxx:21,110 and MultiplyImageFilter
+// NormalizedGaussianConvolutionImageFilter.hxx:48-49), once per call for all scales.
+// It exists because per-lane sub-dword loads are slow on gfx950 (a wave-instruction of
+// byte loads was measured at ~64 cycles in the TA): here every lane moves 4 voxels
+// with one vector load per input, and the line kernels then only read floats.
+// msk == nullptr: tc = float(image) only.  cf == nullptr: not written.
+template <typename TI, typename TM>
+__global__ __launch_bounds__(256) void prep_kernel_vec4(const TI *__restrict__ img,
+                                                        const TM *__restrict__ msk,
+                                                        float *__restrict__ tc,
+                                                        float *__restrict__ cf, int64_t n4) {
+  typedef TI TI4 __attribute__((ext_vector_type(4)));
+  typedef TM TM4 __attribute__((ext_vector_type(4)));
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    const TI4 a = reinterpret_cast<const TI4 *>(img)[i];
+    float4 t = make_float4((float)a.x, (float)a.y, (float)a.z, (float)a.w);
+    if (msk != nullptr) {
+      const TM4 m = reinterpret_cast<const TM4 *>(msk)[i];
+      const float4 c = make_float4((float)m.x, (float)m.y, (float)m.z, (float)m.w);
+      t.x *= c.x; t.y *= c.y; t.z *= c.z; t.w *= c.w;
+      if (cf != nullptr) reinterpret_cast<float4 *>(cf)[i] = c;
+    }
+    reinterpret_cast<float4 *>(tc)[i] = t;
+  }
+}
+template <typename TI, typename TM>
+__global__ __launch_bounds__(256) void prep_kernel_scalar(const TI *__restrict__ img,
+                                                          const TM *__restrict__ msk,
+                                                          float *__restrict__ tc,
+                                                          float *__restrict__ cf, int64_t i0,
+                                                          int64_t n) {
+  int64_t i = i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float t = (float)img[i];
+    if (msk != nullptr) {
+      const float c = (float)msk[i];
+      t *= c;
+      if (cf != nullptr) cf[i] = c;
+    }
+    tc[i] = t;
+  }
 }
 
 // DivideImageFilter on its own, for the NormalizedGaussianConvolution entry point

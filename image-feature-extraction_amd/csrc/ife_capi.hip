@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "feature_kernels.hpp"
@@ -29,10 +30,11 @@ enum KernelKind {
   KK_EIG_BATCH,
   KK_DIVIDE,
   KK_MASK,
+  KK_PREP,
   KK_COUNT
 };
 const char *kKindNames[KK_COUNT] = {"iir_z", "iir_x", "iir_y", "features",
-                                    "eig_batch", "divide", "mask_f64"};
+                                    "eig_batch", "divide", "mask_f64", "prep"};
 
 struct DevBuf {
   void *p = nullptr;
@@ -58,6 +60,7 @@ struct ife_ctx {
   int zchunk = 64;
   int iir_block = 16;
   DevBuf fld[4];  // num ping/pong, den ping/pong
+  DevBuf pre[2];  // image*certainty and certainty as float (prepass, shared by all scales)
   DevBuf ck_y, ck_x;
   DevBuf st_img, st_mask, st_aux, st_out;  // HOST-mode staging
   std::vector<ProfRec> prof;
@@ -295,6 +298,29 @@ int launch_contig(ife_ctx *ctx, const float *in, float *out, const ife_volume_de
   return IFE_OK;
 }
 
+template <typename TI, typename TM>
+int launch_prep(ife_ctx *ctx, const TI *img, const TM *msk, float *tc, float *cf, int64_t n) {
+  ProfScope ps(ctx, KK_PREP);
+  const uintptr_t al = reinterpret_cast<uintptr_t>(img) % (4 * sizeof(TI)) |
+                       reinterpret_cast<uintptr_t>(msk) % (4 * sizeof(TM)) |
+                       reinterpret_cast<uintptr_t>(tc) % 16 | reinterpret_cast<uintptr_t>(cf) % 16;
+  const int64_t n4 = al == 0 ? n / 4 : 0;
+  if (n4 > 0) {
+    const unsigned blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, 8192);
+    hipLaunchKernelGGL((prep_kernel_vec4<TI, TM>), dim3(blocks), dim3(256), 0, ctx->stream, img,
+                       msk, tc, cf, n4);
+    IFE_HIP(ctx, hipGetLastError());
+  }
+  if (n4 * 4 < n) {
+    const int64_t rest = n - n4 * 4;
+    const unsigned blocks = (unsigned)std::min<int64_t>((rest + 255) / 256, 8192);
+    hipLaunchKernelGGL((prep_kernel_scalar<TI, TM>), dim3(blocks), dim3(256), 0, ctx->stream,
+                       img, msk, tc, cf, n4 * 4, n);
+    IFE_HIP(ctx, hipGetLastError());
+  }
+  return IFE_OK;
+}
+
 // SmoothingRecursiveGaussianImageFilter: Z pass from `src`, then X, then Y.
 // Result lands in buf_a (buf_b is the intermediate).
 template <typename SRC>
@@ -387,17 +413,22 @@ static int emphysema_typed(ife_ctx *ctx, const TI *img, const TM *msk, const ife
   const size_t n = (size_t)(vol->nx * vol->ny * vol->nz);
   float *num = (float *)ctx->fld[0].p, *numb = (float *)ctx->fld[1].p;
   float *den = (float *)ctx->fld[2].p, *denb = (float *)ctx->fld[3].p;
+  float *tc = (float *)ctx->pre[0].p, *cf = (float *)ctx->pre[1].p;
+  // Cast + Multiply once for all scales (the reference redoes them per scale, a9).
+  // mask == NULL: certainty == 1 everywhere, image*1 is the image and G(1) is exactly
+  // 1.0f at every voxel (DESIGN.md "all-ones certainty"), so the denominator is skipped.
+  const float *src_num;
+  if (msk == nullptr && std::is_same<TI, float>::value) {
+    src_num = reinterpret_cast<const float *>(img);
+  } else {
+    int rc = launch_prep<TI, TM>(ctx, img, msk, tc, msk ? cf : nullptr, (int64_t)n);
+    if (rc) return rc;
+    src_num = tc;
+  }
   for (int s = 0; s < n_sigmas; ++s) {
     const double sigma = (double)sigmas[s];
-    int rc;
-    if (msk) {
-      rc = smooth_field(ctx, SrcMul<TI, TM>{img, msk}, num, numb, vol, sigma);
-      if (!rc) rc = smooth_field(ctx, SrcImg<TM>{msk}, den, denb, vol, sigma);
-    } else {
-      // certainty == 1 everywhere: image*1 is the image, and G(1) is exactly 1.0f at
-      // every voxel (DESIGN.md "all-ones certainty"), so A/B == A.
-      rc = smooth_field(ctx, SrcImg<TI>{img}, num, numb, vol, sigma);
-    }
+    int rc = smooth_field(ctx, SrcF32{src_num}, num, numb, vol, sigma);
+    if (!rc && msk) rc = smooth_field(ctx, SrcF32{cf}, den, denb, vol, sigma);
     if (rc) return rc;
     rc = launch_features<FEAT_FEATURES8>(ctx, ValSmooth{num, msk ? den : nullptr}, msk,
                                          dout + (size_t)s * n * IFE_NUM_FEATURES, vol, layout);
@@ -405,7 +436,6 @@ static int emphysema_typed(ife_ctx *ctx, const TI *img, const TM *msk, const ife
   }
   return IFE_OK;
 }
-
 
 // =====================================================================================
 extern "C" {
@@ -439,7 +469,8 @@ void ife_ctx_destroy(ife_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  DevBuf *bufs[] = {&ctx->fld[0], &ctx->fld[1], &ctx->fld[2], &ctx->fld[3], &ctx->ck_y,
+  DevBuf *bufs[] = {&ctx->fld[0], &ctx->fld[1], &ctx->fld[2], &ctx->fld[3], &ctx->pre[0],
+                    &ctx->pre[1], &ctx->ck_y,
                     &ctx->ck_x,   &ctx->st_img, &ctx->st_mask, &ctx->st_aux, &ctx->st_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
@@ -491,6 +522,7 @@ int ife_ctx_reserve(ife_ctx *ctx, const ife_volume_desc *vol) {
   if (rc) return rc;
   const size_t nb = (size_t)(vol->nx * vol->ny * vol->nz) * sizeof(float);
   for (int i = 0; i < 4 && !rc; ++i) rc = ensure(ctx, ctx->fld[i], nb);
+  for (int i = 0; i < 2 && !rc; ++i) rc = ensure(ctx, ctx->pre[i], nb);
   if (!rc) rc = ensure_ck(ctx, vol);
   return rc;
 }
@@ -578,7 +610,10 @@ int ife_normalized_gaussian_convolution(ife_ctx *ctx, const float *image,
   if ((rc = stage_out_begin(ctx, mem, out, n * 4, &dO))) return rc;
   float *num = (float *)ctx->fld[0].p, *numb = (float *)ctx->fld[1].p;
   float *den = (float *)ctx->fld[2].p, *denb = (float *)ctx->fld[3].p;
-  rc = smooth_field(ctx, SrcMulF{(const float *)dI, (const float *)dC}, num, numb, vol, sigma);
+  float *tc = (float *)ctx->pre[0].p;
+  rc = launch_prep<float, float>(ctx, (const float *)dI, (const float *)dC, tc, nullptr,
+                                 (int64_t)n);
+  if (!rc) rc = smooth_field(ctx, SrcF32{tc}, num, numb, vol, sigma);
   if (!rc) rc = smooth_field(ctx, SrcF32{(const float *)dC}, den, denb, vol, sigma);
   if (rc) return rc;
   {

@@ -187,7 +187,6 @@ struct SrcMul {
   }
 };
 using SrcMulF = SrcMul<float, float>;
-
 struct Checkpoint {
   double *y;  // [nblocks][4][nlines]
   float *x;   // [nblocks][3][nlines]
