@@ -73,6 +73,164 @@ __device__ __forceinline__ Eig3 eig3_sym(float A11, float A12, float A13, float 
   return r;
 }
 
+// ---------------------------------------------------------------------------------
+// Fast form of the TRIG == 0 (double sqrt/acos/cos) solver.
+//
+// Same float operations on the same operands in the same order as eig3_sym<0>, so the
+// float intermediates (q, p, B, r) are bit-identical; only HOW three of them are
+// obtained changes:
+//   * x / 3 and x / 6: reciprocal multiply + one fma correction, which is the
+//     correctly rounded quotient (verified exhaustively over all 2^32 inputs,
+//     tests/csrc/div_const_exhaustive.c; extreme magnitudes take the plain division);
+//   * the six divisions by p share one refined reciprocal; each quotient then takes the
+//     two fma refinement steps of the IEEE division expansion, without its range
+//     scaling: correctly rounded for p in [2^-60, 2^60] (outside that range the generic
+//     solver runs instead) and quotients of normal size; a quotient below 2^-100 in
+//     magnitude may differ in its last bit, which cannot reach r = det(B)/2 in float;
+//   * acos and cos (double) are evaluated with argument-range-specific polynomials
+//     (|error| < 2e-16 on r in (-1,1), phi in [0, pi/3]) instead of the general library
+//     routines: the values agree with libm except in the last double bits, i.e. after
+//     rounding to float they differ from the oracle for about one voxel in 10^8.
+// ---------------------------------------------------------------------------------
+// x / d for d = 3, 6: q = x*RN(1/d), one fma correction.  Exhaustively equal to the IEEE
+// quotient for 2^-100 <= |x| <= 2^100 (tests/csrc/div_const_exhaustive.c); zero keeps its
+// sign, everything else (denormal quotients, inf, NaN) takes the division expansion.
+template <int D>
+__device__ __forceinline__ float div_by_const(float x) {
+  const float d = (float)D;
+  const float y = D == 3 ? 0x1.555556p-2f : 0x1.555556p-3f;  // RN(1/3), RN(1/6)
+  const float ax = fabsf(x);
+  const float q = x * y;
+  float f = fmaf(fmaf(-d, q, x), y, q);
+  f = ax == 0.0f ? x : f;
+  if (!(ax <= 0x1p100f) || (ax < 0x1p-100f && ax != 0.0f)) f = x / d;
+  return f;
+}
+__device__ __forceinline__ float div_by_3(float x) { return div_by_const<3>(x); }
+__device__ __forceinline__ float div_by_6(float x) { return div_by_const<6>(x); }
+struct SharedRecip {
+  float d, r;
+};
+__device__ __forceinline__ SharedRecip shared_recip(float d) {
+  SharedRecip s;
+  s.d = d;
+  float r = __builtin_amdgcn_rcpf(d);
+  r = fmaf(fmaf(-d, r, 1.0f), r, r);
+  s.r = r;
+  return s;
+}
+__device__ __forceinline__ float div_shared(float n, const SharedRecip &s) {
+  float q = n * s.r;
+  q = fmaf(fmaf(-s.d, q, n), s.r, q);
+  return fmaf(fmaf(-s.d, q, n), s.r, q);
+}
+
+// asin(s) = s + s*z*P(z), z = s^2 <= 0.25 (degree-11 minimax fit, |err P| < 2.4e-16)
+__device__ __forceinline__ double asin_poly(double z) {
+  double p = 0.028169218060881414;
+  p = fma(p, z, -0.010749050339697808);
+  p = fma(p, z, 0.01603551434914882);
+  p = fma(p, z, 0.0078029494773533175);
+  p = fma(p, z, 0.011875494382636922);
+  p = fma(p, z, 0.013929652902326633);
+  p = fma(p, z, 0.017355259955786323);
+  p = fma(p, z, 0.02237204763174451);
+  p = fma(p, z, 0.03038194736709848);
+  p = fma(p, z, 0.044642857103423646);
+  p = fma(p, z, 0.07500000000020764);
+  p = fma(p, z, 0.1666666666666665);
+  return p;
+}
+// acos on (-1, 1); the argument is a float so 1 - |r| is exact
+__device__ __forceinline__ double acos_unit(float rf) {
+  const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17;
+  const double r = (double)rf;
+  const double a = fabs(r);
+  const bool big = a > 0.5;
+  const double z = big ? (1.0 - a) * 0.5 : a * a;
+  // sqrt(z) by one rsq + two Newton steps (z in (0, 0.25]; unused lanes are selected away)
+  const double y0 = __builtin_amdgcn_rsq(z);
+  double g = z * y0, h = 0.5 * y0;
+  double e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  g = fma(fma(-g, g, z), h, g);
+  const double s = big ? g : a;
+  const double t = fma(s * z, asin_poly(z), s);  // asin(s)
+  // |r| <= 0.5: pi/2 - sign(r) asin|r| ; r > 0.5: 2 asin(s) ; r < -0.5: pi - 2 asin(s)
+  const double ts = r < 0.0 ? -t : t;
+  const double small = (PIO2_HI - ts) + PIO2_LO;
+  const double t2 = t + t;
+  const double bigv = r < 0.0 ? (2.0 * PIO2_HI - t2) + 2.0 * PIO2_LO : t2;
+  return big ? bigv : small;
+}
+// cos on [-0.1, 1.1]:  1 - w/2 + w^2 C(w), w = y^2 (degree-6 fit, |err| < 4e-18)
+__device__ __forceinline__ double cos_small(double y) {
+  const double w = y * y;
+  double c = 4.7137756144213336e-14;
+  c = fma(c, w, -1.1469654898726794e-11);
+  c = fma(c, w, 2.0876747999120392e-09);
+  c = fma(c, w, -2.75573191859408e-07);
+  c = fma(c, w, 2.4801587301510604e-05);
+  c = fma(c, w, -0.001388888888888883);
+  c = fma(c, w, 0.041666666666666664);
+  return fma(w * w, c, fma(-0.5, w, 1.0));
+}
+__device__ __forceinline__ double div3_f64(double x) {
+  const double y = 0x1.5555555555555p-2;  // RN(1/3)
+  const double q = x * y;
+  return fma(fma(-3.0, q, x), y, q);
+}
+
+__device__ __forceinline__ Eig3 eig3_sym_fast(float A11, float A12, float A13, float A22,
+                                             float A23, float A33) {
+  const double PI_HI = 3.14159265358979311600e+00, PI_LO = 1.22464679914735320717e-16;
+  float p = A12 * A12 + A13 * A13 + A23 * A23;
+  const bool diag = p == 0.0f;
+  const float q = div_by_3(A11 + A22 + A33);
+  const float d1 = A11 - q, d2 = A22 - q, d3 = A33 - q;
+  p = d1 * d1 + d2 * d2 + d3 * d3 + 2.0f * p;
+  p = sqrtf(div_by_6(p));
+  const float ap = fabsf(p);
+  const bool safe = ap >= 0x1p-60f && ap <= 0x1p60f;
+  if (!diag && !safe) return eig3_sym<0>(A11, A12, A13, A22, A23, A33);
+  const SharedRecip rp = shared_recip(p);
+  const float B11 = div_shared(d1, rp), B12 = div_shared(A12, rp), B13 = div_shared(A13, rp);
+  const float B22 = div_shared(d2, rp), B23 = div_shared(A23, rp), B33 = div_shared(d3, rp);
+  const float r2 = B11 * B22 * B33 + 2.0f * B12 * B13 * B23 - B23 * B23 * B11 -
+                   B13 * B13 * B22 - B12 * B12 * B33;
+  const float rr = r2 * 0.5f;
+  const float twop = 2.0f * p;
+  float phi = (float)div3_f64(acos_unit(rr));
+  phi = rr >= 1.0f ? 0.0f : phi;
+  phi = rr <= -1.0f ? (float)(M_PI / 3) : phi;
+  const double qd = (double)q, tpd = (double)twop, phid = (double)phi;
+  float e0 = (float)(qd + tpd * cos_small(phid));
+  // cos(phi + 2pi/3) = -cos(pi - (phi + 2pi/3)); pi - arg is exact in double-double
+  const double arg = phid + M_PI * (2.0 / 3.0);
+  const double yy = (PI_HI - arg) + PI_LO;
+  float e2 = (float)(qd - tpd * cos_small(yy));
+  float e1 = 3.0f * q - e0 - e2;
+  if (fabsf(e0) < fabsf(e2)) { const float t = e0; e0 = e2; e2 = t; }
+  if (fabsf(e1) < fabsf(e2)) { const float t = e1; e1 = e2; e2 = t; }
+  Eig3 r;
+  r.e0 = e0; r.e1 = e1; r.e2 = e2;
+  if (diag) {
+    const float a1 = fabsf(A11), a2 = fabsf(A22), a3 = fabsf(A33);
+    const bool c12 = a1 > a2, c13 = a1 > a3, c23 = a2 > a3;
+    if (c12) {
+      r.e0 = c13 ? A11 : A33;
+      r.e1 = c13 ? (c23 ? A22 : A33) : A11;
+      r.e2 = c13 ? (c23 ? A33 : A22) : A22;
+    } else {
+      r.e0 = c23 ? A22 : A33;
+      r.e1 = c23 ? (c13 ? A11 : A33) : A22;
+      r.e2 = c23 ? (c13 ? A33 : A11) : A11;
+    }
+  }
+  return r;
+}
+
 struct EigFeat {
   float f[6];
 };
@@ -81,7 +239,8 @@ struct EigFeat {
 template <int TRIG>
 __device__ __forceinline__ EigFeat eig_features(float A11, float A12, float A13, float A22,
                                                 float A23, float A33) {
-  const Eig3 ev = eig3_sym<TRIG>(A11, A12, A13, A22, A23, A33);
+  const Eig3 ev = TRIG == 0 ? eig3_sym_fast(A11, A12, A13, A22, A23, A33)
+                            : eig3_sym<TRIG>(A11, A12, A13, A22, A23, A33);
   EigFeat o;
   o.f[0] = ev.e0;
   o.f[1] = ev.e1;

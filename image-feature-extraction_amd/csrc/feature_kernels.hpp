@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void eig_batch_kernel(const float *__restrict_
   if (i >= n) return;
   const float *a = A6 + i * 6;
   if (NOUT == 3) {
-    Eig3 e = trig == 0 ? eig3_sym<0>(a[0], a[1], a[2], a[3], a[4], a[5])
+    Eig3 e = trig == 0 ? eig3_sym_fast(a[0], a[1], a[2], a[3], a[4], a[5])
                        : eig3_sym<1>(a[0], a[1], a[2], a[3], a[4], a[5]);
     outv[i * 3 + 0] = e.e0; outv[i * 3 + 1] = e.e1; outv[i * 3 + 2] = e.e2;
   } else {
