@@ -182,6 +182,14 @@ __device__ __forceinline__ double div3_f64(double x) {
   return fma(fma(-3.0, q, x), y, q);
 }
 
+// Out-of-line copy of the generic solver for the rare out-of-range fallback, so that its
+// register needs (the library cos with large-argument reduction) do not set the
+// kernel's allocation.
+__device__ __noinline__ Eig3 eig3_sym_generic_call(float A11, float A12, float A13, float A22,
+                                                   float A23, float A33) {
+  return eig3_sym<0>(A11, A12, A13, A22, A23, A33);
+}
+
 __device__ __forceinline__ Eig3 eig3_sym_fast(float A11, float A12, float A13, float A22,
                                              float A23, float A33) {
   const double PI_HI = 3.14159265358979311600e+00, PI_LO = 1.22464679914735320717e-16;
@@ -193,7 +201,7 @@ __device__ __forceinline__ Eig3 eig3_sym_fast(float A11, float A12, float A13, f
   p = sqrtf(div_by_6(p));
   const float ap = fabsf(p);
   const bool safe = ap >= 0x1p-60f && ap <= 0x1p60f;
-  if (!diag && !safe) return eig3_sym<0>(A11, A12, A13, A22, A23, A33);
+  if (!diag && !safe) return eig3_sym_generic_call(A11, A12, A13, A22, A23, A33);
   const SharedRecip rp = shared_recip(p);
   const float B11 = div_shared(d1, rp), B12 = div_shared(A12, rp), B13 = div_shared(A13, rp);
   const float B22 = div_shared(d2, rp), B23 = div_shared(A23, rp), B33 = div_shared(d3, rp);

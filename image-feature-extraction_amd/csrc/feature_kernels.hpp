@@ -16,11 +16,10 @@
 // gradient magnitude accumulates g*g in double and casts sqrt to float.
 //
 // Mapping: a workgroup of 512 threads owns a 64 x 8 XY tile and marches along z.
-// Each plane is staged once (with a one-voxel replicate halo) in an LDS tile,
-// double buffered so that one barrier per plane suffices; the global loads of plane
-// p+1 are issued before plane p is consumed.  Per thread a three-plane ring of
-// centre values and first differences lives in registers, so every smoothed value is
-// read from HBM once per z-chunk (plus halo) and every output written once.
+// Each plane is staged once (with a one-voxel replicate halo) in an LDS tile; a ring
+// of four tiles keeps planes z-1, z, z+1 resident while plane z+2 is in flight, so
+// every smoothed value is read from HBM once per z-chunk (plus halo) and every output
+// written once.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
@@ -96,14 +95,28 @@ constexpr int FT_TX = 64;
 constexpr int FT_TY = 8;
 constexpr int FT_HX = FT_TX + 2;
 constexpr int FT_HY = FT_TY + 2;
-constexpr int FT_NE = FT_HX * FT_HY;  // 660 staged elements per plane
+constexpr int FT_NE = FT_HX * FT_HY;  // staged elements per plane (tile + halo)
 constexpr int FT_THREADS = FT_TX * FT_TY;
+constexpr int FT_NLD = (FT_NE + FT_THREADS - 1) / FT_THREADS;  // staged elements per thread
 
-template <int MODE, typename VAL, typename TM>
+// One workgroup owns a 64 x FT_TY XY tile and marches along z.  Four LDS slots hold the
+// tile (with replicate halo) of planes z-1, z, z+1 and the plane being written for the
+// next step, so one barrier per plane suffices; a thread reads its 19 stencil points
+// from LDS and carries nothing from plane to plane (short live ranges: the eigen solve
+// is the register peak, not a ring of per-plane state).
+//
+// UNIT = all spacings are exactly 1: the operator coefficients are +-0.5 and 1,-2,1, so
+//  * a first difference kept as a float image, float(0.5*b - 0.5*a) accumulated in double,
+//    equals 0.5f*(b - a) in float (b - a rounds once; a 53-bit intermediate can never sit
+//    on a float rounding boundary unless it is exact; scaling by 0.5 is exact);
+//  * a second difference float((a - 2c) + b) takes one fma (2c is exact) and one add.
+// Both forms are bit-identical to the generic inner products, except that the sign of
+// an exact zero is not tracked (+0/-0 compare equal and never reach a non-zero output).
+template <int MODE, bool UNIT, int TRIG, typename VAL, typename TM>
 __global__ __launch_bounds__(FT_THREADS) void features_kernel(VAL val, const TM *__restrict__ mask,
                                                               float *__restrict__ out, FeatGeom g,
-                                                              DerivCoef dc, int planar, int trig) {
-  __shared__ float tile[2][FT_HY][FT_HX];
+                                                              DerivCoef dc, int planar) {
+  __shared__ float tile[4][FT_HY][FT_HX];
   // mask tile of the output plane, staged as dwords (per-lane sub-dword global loads are
   // slow on gfx950); row pitch = 64 mask elements
   constexpr int MT_DW = FT_TY * FT_TX * (int)sizeof(TM) / 4;  // dwords per plane tile
@@ -120,26 +133,18 @@ __global__ __launch_bounds__(FT_THREADS) void features_kernel(VAL val, const TM 
   const int z1 = min(z0 + g.zchunk, g.nz);
   const bool inb = x < g.nx && y < g.ny;
 
-  // staging assignment: elements tid and tid+512 of the (HY x HX) halo tile
-  const int e0 = tid, e1 = tid + FT_THREADS;
-  const bool has1 = e1 < FT_NE;
-  const int e0y = e0 / FT_HX, e0x = e0 % FT_HX;
-  const int e1y = has1 ? e1 / FT_HX : 0, e1x = has1 ? e1 % FT_HX : 0;
-  const int64_t off0 = (int64_t)clampi(blockIdx.x * FT_TX - 1 + e0x, g.nx - 1) +
-                       (int64_t)g.nx * clampi(blockIdx.y * FT_TY - 1 + e0y, g.ny - 1);
-  const int64_t off1 = (int64_t)clampi(blockIdx.x * FT_TX - 1 + e1x, g.nx - 1) +
-                       (int64_t)g.nx * clampi(blockIdx.y * FT_TY - 1 + e1y, g.ny - 1);
-
-  float c_m = 0, c_0 = 0, c_p = 0;
-  float dx_m = 0, dx_0 = 0, dx_p = 0, dy_m = 0, dy_0 = 0, dy_p = 0;
-  float dxx_0 = 0, dxx_p = 0, dyy_0 = 0, dyy_p = 0, dxy_0 = 0, dxy_p = 0;
-  double axy_0 = 0, axy_p = 0;
-
-  float r0, r1 = 0.0f;
-  {
-    const int64_t pb = (int64_t)clampi(z0 - 1, g.nz - 1) * g.plane;
-    r0 = val.ld(pb + off0);
-    if (has1) r1 = val.ld(pb + off1);
+  // staging assignment: elements tid + k*FT_THREADS of the (HY x HX) halo tile
+  int64_t off[FT_NLD];
+  int eidx[FT_NLD];
+  bool has[FT_NLD];
+#pragma unroll
+  for (int k = 0; k < FT_NLD; ++k) {
+    const int e = tid + k * FT_THREADS;
+    has[k] = e < FT_NE;
+    const int ey = has[k] ? e / FT_HX : 0, ex = has[k] ? e % FT_HX : 0;
+    eidx[k] = ey * FT_HX + ex;
+    off[k] = (int64_t)clampi(blockIdx.x * FT_TX - 1 + ex, g.nx - 1) +
+             (int64_t)g.nx * clampi(blockIdx.y * FT_TY - 1 + ey, g.ny - 1);
   }
   // mask staging: thread t < MT_DW owns dword (t % MT_DWROW) of tile row (t / MT_DWROW).
   // Vector form needs rows that are dword multiples and a dword-aligned base.
@@ -150,108 +155,138 @@ __global__ __launch_bounds__(FT_THREADS) void features_kernel(VAL val, const TM 
   const int my = blockIdx.y * FT_TY + mrow;
   const bool mine = mvec && tid < MT_DW && mx < g.nx && my < g.ny;
   const int64_t moff = (int64_t)mx + (int64_t)g.nx * my;  // element offset inside a plane
-  uint32_t mr = 0;
 
-  for (int p = z0 - 1; p <= z1; ++p) {
-    const int buf = (p - (z0 - 1)) & 1;
-    tile[buf][e0y][e0x] = r0;
-    if (has1) tile[buf][e1y][e1x] = r1;
-    if (mine) mtile[buf][tid] = mr;  // mask of plane p-1, loaded one iteration ago
-    if (p < z1) {  // issue the next plane's loads before consuming this one
-      const int64_t pb = (int64_t)clampi(p + 1, g.nz - 1) * g.plane;
-      r0 = val.ld(pb + off0);
-      if (has1) r1 = val.ld(pb + off1);
-      // plane p is the output plane of the next iteration
-      if (mine && p >= z0)
-        mr = *reinterpret_cast<const uint32_t *>(mask + (int64_t)p * g.plane + moff);
+  float r[FT_NLD];
+  uint32_t mr = 0;
+  auto load_plane = [&](int p) {
+    const int64_t pb = (int64_t)clampi(p, g.nz - 1) * g.plane;
+#pragma unroll
+    for (int k = 0; k < FT_NLD; ++k)
+      if (has[k]) r[k] = val.ld(pb + off[k]);
+  };
+  auto store_plane = [&](int p) {
+    float *t = &tile[(p - (z0 - 1)) & 3][0][0];
+#pragma unroll
+    for (int k = 0; k < FT_NLD; ++k)
+      if (has[k]) t[eidx[k]] = r[k];
+  };
+
+  load_plane(z0 - 1);
+  store_plane(z0 - 1);
+  load_plane(z0);
+  store_plane(z0);
+  load_plane(z0 + 1);
+  if (mine) mr = *reinterpret_cast<const uint32_t *>(mask + (int64_t)z0 * g.plane + moff);
+
+  for (int z = z0; z < z1; ++z) {
+    store_plane(z + 1);
+    if (mine) mtile[z & 1][tid] = mr;
+    if (z + 1 < z1) {  // issue the next step's loads before consuming this one
+      load_plane(z + 2);
+      if (mine) mr = *reinterpret_cast<const uint32_t *>(mask + (int64_t)(z + 1) * g.plane + moff);
     }
     __syncthreads();
+    if (!inb) continue;
 
-    // in-plane quantities of plane p at (x, y); tile coordinates are +1
-    const float (*t)[FT_HX] = tile[buf];
-    const float fc = t[ty + 1][tx + 1];
-    const float fxm = t[ty + 1][tx], fxp = t[ty + 1][tx + 2];
-    const float fym = t[ty][tx + 1], fyp = t[ty + 2][tx + 1];
-    const double gx = d1(dc.m1[0], dc.p1[0], fxm, fxp);
-    const double gy = d1(dc.m1[1], dc.p1[1], fym, fyp);
-
-    c_m = c_0; c_0 = c_p; c_p = fc;
-    dx_m = dx_0; dx_0 = dx_p; dx_p = (float)gx;
-    dy_m = dy_0; dy_0 = dy_p; dy_p = (float)gy;
-    if (NEED_G) {
-      axy_0 = axy_p;
-      double a = 0.0;
-      a += gx * gx;
-      a += gy * gy;
-      axy_p = a;
-    }
-    if (NEED_H) {
-      dxx_0 = dxx_p; dyy_0 = dyy_p; dxy_0 = dxy_p;
-      dxx_p = d2(dc.a2[0], dc.b2[0], dc.c2[0], fxm, fc, fxp);
-      dyy_p = d2(dc.a2[1], dc.b2[1], dc.c2[1], fym, fc, fyp);
-      // Dxy = D_y(Dx): Dx (as a float image) at rows y-1 and y+1
-      const float dx_ym = (float)d1(dc.m1[0], dc.p1[0], t[ty][tx], t[ty][tx + 2]);
-      const float dx_yp = (float)d1(dc.m1[0], dc.p1[0], t[ty + 2][tx], t[ty + 2][tx + 2]);
-      dxy_p = (float)d1(dc.m1[1], dc.p1[1], dx_ym, dx_yp);
-    }
-
-    const int z = p - 1;
-    if (z >= z0 && inb) {
-      const int64_t idx = (int64_t)x + (int64_t)g.nx * ((int64_t)y + (int64_t)g.ny * z);
-      bool keep = true;
-      if (mvec)
-        keep = reinterpret_cast<const TM *>(mtile[buf])[ty * FT_TX + tx] != (TM)0;
-      else if (mask != nullptr)
-        keep = mask[idx] != (TM)0;
-      float o[NOUT];
+    const int64_t idx = (int64_t)x + (int64_t)g.nx * ((int64_t)y + (int64_t)g.ny * z);
+    bool keep = true;
+    if (mvec)
+      keep = reinterpret_cast<const TM *>(mtile[z & 1])[ty * FT_TX + tx] != (TM)0;
+    else if (mask != nullptr)
+      keep = mask[idx] != (TM)0;
+    float o[NOUT];
 #pragma unroll
-      for (int k = 0; k < NOUT; ++k) o[k] = 0.0f;
-      if (keep) {
-        float G = 0.0f;
-        if (NEED_G) {
-          const double gz = d1(dc.m1[2], dc.p1[2], c_m, c_p);
-          double a = axy_0;
-          a += gz * gz;
-          G = (float)sqrt(a);
-        }
-        if constexpr (MODE == FEAT_GRADMAG) {
-          o[0] = G;
+    for (int k = 0; k < NOUT; ++k) o[k] = 0.0f;
+    if (keep) {
+      const float(*tm)[FT_HX] = tile[(z - 1 - (z0 - 1)) & 3];
+      const float(*t0)[FT_HX] = tile[(z - (z0 - 1)) & 3];
+      const float(*tp)[FT_HX] = tile[(z + 1 - (z0 - 1)) & 3];
+      const float c = t0[ty + 1][tx + 1];
+      const float xm = t0[ty + 1][tx], xp = t0[ty + 1][tx + 2];
+      const float ym = t0[ty][tx + 1], yp = t0[ty + 2][tx + 1];
+      const float zm = tm[ty + 1][tx + 1], zp = tp[ty + 1][tx + 1];
+      float G = 0.0f;
+      if (NEED_G) {
+        double gx, gy, gz;
+        if (UNIT) {
+          gx = 0.5 * ((double)xp - (double)xm);
+          gy = 0.5 * ((double)yp - (double)ym);
+          gz = 0.5 * ((double)zp - (double)zm);
         } else {
-          const float dzz = d2(dc.a2[2], dc.b2[2], dc.c2[2], c_m, c_0, c_p);
-          const float dxz = (float)d1(dc.m1[2], dc.p1[2], dx_m, dx_p);
-          const float dyz = (float)d1(dc.m1[2], dc.p1[2], dy_m, dy_p);
-          if constexpr (MODE == FEAT_HESSIAN6) {
-            o[0] = dxx_0; o[1] = dxy_0; o[2] = dxz; o[3] = dyy_0; o[4] = dyz; o[5] = dzz;
+          gx = d1(dc.m1[0], dc.p1[0], xm, xp);
+          gy = d1(dc.m1[1], dc.p1[1], ym, yp);
+          gz = d1(dc.m1[2], dc.p1[2], zm, zp);
+        }
+        double a = gx * gx;
+        a += gy * gy;
+        a += gz * gz;
+        G = (float)sqrt(a);
+      }
+      if constexpr (MODE == FEAT_GRADMAG) {
+        o[0] = G;
+      } else if (NEED_H) {
+        // first differences as float images at the six neighbours, then chained
+        const float cmm = t0[ty][tx], cpm = t0[ty][tx + 2];
+        const float cmp = t0[ty + 2][tx], cpp = t0[ty + 2][tx + 2];
+        const float zm_xm = tm[ty + 1][tx], zm_xp = tm[ty + 1][tx + 2];
+        const float zm_ym = tm[ty][tx + 1], zm_yp = tm[ty + 2][tx + 1];
+        const float zp_xm = tp[ty + 1][tx], zp_xp = tp[ty + 1][tx + 2];
+        const float zp_ym = tp[ty][tx + 1], zp_yp = tp[ty + 2][tx + 1];
+        float dxx, dyy, dzz, dxy, dxz, dyz;
+        if (UNIT) {
+          const float dx_ym = 0.5f * (cpm - cmm), dx_yp = 0.5f * (cpp - cmp);
+          const float dx_zm = 0.5f * (zm_xp - zm_xm), dx_zp = 0.5f * (zp_xp - zp_xm);
+          const float dy_zm = 0.5f * (zm_yp - zm_ym), dy_zp = 0.5f * (zp_yp - zp_ym);
+          dxy = 0.5f * (dx_yp - dx_ym);
+          dxz = 0.5f * (dx_zp - dx_zm);
+          dyz = 0.5f * (dy_zp - dy_zm);
+          const double cd = (double)c;
+          dxx = (float)(fma(-2.0, cd, (double)xm) + (double)xp);
+          dyy = (float)(fma(-2.0, cd, (double)ym) + (double)yp);
+          dzz = (float)(fma(-2.0, cd, (double)zm) + (double)zp);
+        } else {
+          const float dx_ym = (float)d1(dc.m1[0], dc.p1[0], cmm, cpm);
+          const float dx_yp = (float)d1(dc.m1[0], dc.p1[0], cmp, cpp);
+          const float dx_zm = (float)d1(dc.m1[0], dc.p1[0], zm_xm, zm_xp);
+          const float dx_zp = (float)d1(dc.m1[0], dc.p1[0], zp_xm, zp_xp);
+          const float dy_zm = (float)d1(dc.m1[1], dc.p1[1], zm_ym, zm_yp);
+          const float dy_zp = (float)d1(dc.m1[1], dc.p1[1], zp_ym, zp_yp);
+          dxy = (float)d1(dc.m1[1], dc.p1[1], dx_ym, dx_yp);
+          dxz = (float)d1(dc.m1[2], dc.p1[2], dx_zm, dx_zp);
+          dyz = (float)d1(dc.m1[2], dc.p1[2], dy_zm, dy_zp);
+          dxx = d2(dc.a2[0], dc.b2[0], dc.c2[0], xm, c, xp);
+          dyy = d2(dc.a2[1], dc.b2[1], dc.c2[1], ym, c, yp);
+          dzz = d2(dc.a2[2], dc.b2[2], dc.c2[2], zm, c, zp);
+        }
+        if constexpr (MODE == FEAT_HESSIAN6) {
+          o[0] = dxx; o[1] = dxy; o[2] = dxz; o[3] = dyy; o[4] = dyz; o[5] = dzz;
+        } else {
+          const EigFeat ef = eig_features<TRIG>(dxx, dxy, dxz, dyy, dyz, dzz);
+          if constexpr (MODE == FEAT_FEATURES8) {
+            o[0] = c; o[1] = G;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[2 + k] = ef.f[k];
           } else {
-            EigFeat ef;
-            if (trig == 0) ef = eig_features<0>(dxx_0, dxy_0, dxz, dyy_0, dyz, dzz);
-            else ef = eig_features<1>(dxx_0, dxy_0, dxz, dyy_0, dyz, dzz);
-            if constexpr (MODE == FEAT_FEATURES8) {
-              o[0] = c_0; o[1] = G;
 #pragma unroll
-              for (int k = 0; k < 6; ++k) o[2 + k] = ef.f[k];
-            } else {
-#pragma unroll
-              for (int k = 0; k < 6; ++k) o[k] = ef.f[k];
-            }
+            for (int k = 0; k < 6; ++k) o[k] = ef.f[k];
           }
         }
       }
-      if (planar) {
+    }
+    if (planar) {
 #pragma unroll
-        for (int k = 0; k < NOUT; ++k) out[(int64_t)k * g.nvox + idx] = o[k];
-      } else if constexpr (NOUT == 8) {
-        float4 *q = reinterpret_cast<float4 *>(out + idx * 8);
-        q[0] = make_float4(o[0], o[1], o[2], o[3]);
-        q[1] = make_float4(o[4], o[5], o[6], o[7]);
-      } else if constexpr (NOUT == 6) {
-        float2 *q = reinterpret_cast<float2 *>(out + idx * 6);
-        q[0] = make_float2(o[0], o[1]);
-        q[1] = make_float2(o[2], o[3]);
-        q[2] = make_float2(o[4], o[5]);
-      } else {
-        out[idx] = o[0];
-      }
+      for (int k = 0; k < NOUT; ++k) out[(int64_t)k * g.nvox + idx] = o[k];
+    } else if constexpr (NOUT == 8) {
+      float4 *q = reinterpret_cast<float4 *>(out + idx * 8);
+      q[0] = make_float4(o[0], o[1], o[2], o[3]);
+      q[1] = make_float4(o[4], o[5], o[6], o[7]);
+    } else if constexpr (NOUT == 6) {
+      float2 *q = reinterpret_cast<float2 *>(out + idx * 6);
+      q[0] = make_float2(o[0], o[1]);
+      q[1] = make_float2(o[2], o[3]);
+      q[2] = make_float2(o[4], o[5]);
+    } else {
+      out[idx] = o[0];
     }
   }
 }

@@ -350,8 +350,22 @@ int launch_features(ife_ctx *ctx, VAL val, const TM *mask, float *out,
   if (grid.y > 65535u || grid.z > 65535u)
     return fail(ctx, IFE_E_SIZE, "volume too large for the feature kernel grid");
   ProfScope ps(ctx, KK_FEATURES);
-  hipLaunchKernelGGL((features_kernel<MODE, VAL, TM>), grid, dim3(FT_THREADS), 0, ctx->stream,
-                     val, mask, out, g, dc, layout == IFE_PLANAR ? 1 : 0, ctx->trig_mode);
+  const bool unit = v->sx == 1.0 && v->sy == 1.0 && v->sz == 1.0;
+  const int planar = layout == IFE_PLANAR ? 1 : 0;
+  constexpr bool has_eig = MODE == FEAT_FEATURES8 || MODE == FEAT_EIG6;
+#define IFE_LAUNCH_FEAT(UNIT_, TRIG_)                                                        \
+  hipLaunchKernelGGL((features_kernel<MODE, UNIT_, TRIG_, VAL, TM>), grid, dim3(FT_THREADS), \
+                     0, ctx->stream, val, mask, out, g, dc, planar)
+  if (has_eig && ctx->trig_mode == 1) {
+    if constexpr (has_eig) {
+      if (unit) IFE_LAUNCH_FEAT(true, 1);
+      else IFE_LAUNCH_FEAT(false, 1);
+    }
+  } else {
+    if (unit) IFE_LAUNCH_FEAT(true, 0);
+    else IFE_LAUNCH_FEAT(false, 0);
+  }
+#undef IFE_LAUNCH_FEAT
   IFE_HIP(ctx, hipGetLastError());
   return IFE_OK;
 }
