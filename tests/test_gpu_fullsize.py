@@ -1,0 +1,122 @@
+"""GPU tests at BASELINE.json's full size (512^3): size-independent properties, and --
+since the C oracle finishes a 512^3 scale in seconds on the box's host cores -- one direct
+comparison with the oracle at full size."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 512
+
+
+@pytest.fixture(scope="module")
+def big(synth):
+    shape = (N, N, N)
+    img = synth.volume_f32(shape, synth.SEED_CONFIG[3])
+    mask = np.minimum(synth.mask_ellipsoids(shape), 1).astype(np.uint8)
+    return img, mask
+
+
+@pytest.fixture(scope="module")
+def dev(ife, big):
+    import torch
+    img, mask = big
+    d = {"img": torch.from_numpy(img).cuda(), "mask": torch.from_numpy(mask).cuda(),
+         "out_a": torch.empty((N, N, N, 8), dtype=torch.float32, device="cuda"),
+         "out_b": torch.empty((N, N, N, 8), dtype=torch.float32, device="cuda")}
+    c = ife.Context(0)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    d["ctx"] = c
+    yield d
+    c.close()
+
+
+def run(ife, dev, img, mask, sigma, out, layout=None):
+    import torch
+    dev["ctx"].emphysema_features_device(
+        img.data_ptr(), ife.F32, mask.data_ptr() if mask is not None else None, ife.U8,
+        (N, N, N), (1.0, 1.0, 1.0), [sigma], out.data_ptr(),
+        ife.INTERLEAVED if layout is None else layout)
+    torch.cuda.synchronize()
+
+
+def test_full_size_matches_oracle(ife, oracle, big, dev):
+    """512^3, sigma = 2, ~20 % foreground mask: the whole 8-component output against the
+    oracle.  Smoothed value and gradient magnitude bit exact; eigen features within 1e-6 of
+    |lambda_1| (north_star bar: 1e-5)."""
+    img, mask = big
+    oracle.set_threads(min(16, os.cpu_count() or 1))
+    run(ife, dev, dev["img"], dev["mask"], 2.0, dev["out_a"])
+    got = dev["out_a"].cpu().numpy()
+    ref = oracle.emphysema_features(img, mask, 2.0)
+    assert np.array_equal(got[..., 0], ref[..., 0])
+    assert np.array_equal(got[..., 1], ref[..., 1])
+    worst = 0.0
+    for z in range(0, N, 64):  # blockwise to keep temporaries small
+        g, r = got[z:z + 64, ..., 2:], ref[z:z + 64, ..., 2:]
+        lam = np.maximum(np.abs(r[..., 0]).astype(np.float64), 1e-30)
+        d = np.abs(g.astype(np.float64) - r)
+        worst = max(worst, float((d[..., 0:4] / lam[..., None]).max()),
+                    float((d[..., 5] / lam).max()), float((d[..., 4] / lam ** 3).max()) / 3)
+    exact = float((got == ref).mean())
+    print("512^3 sigma 2: worst error / |lambda1| = %.3g, bit-identical components %.7f"
+          % (worst, exact))
+    assert worst <= 1e-6
+    assert (got[mask == 0] == 0).all()
+
+
+def test_power_of_two_scaling_is_exact_at_full_size(ife, dev):
+    """features(2*image) == 2*features(image) exactly (product: 8x), all three scales."""
+    import torch
+    img2 = dev["img"] * 2.0
+    for sigma in (1.0, 4.0):
+        run(ife, dev, dev["img"], dev["mask"], sigma, dev["out_a"])
+        run(ife, dev, img2, dev["mask"], sigma, dev["out_b"])
+        scale = torch.tensor([2, 2, 2, 2, 2, 2, 8, 2], dtype=torch.float32, device="cuda")
+        assert bool(torch.equal(dev["out_b"], dev["out_a"] * scale))
+    del img2
+
+
+def test_chunking_and_block_size_are_invisible_at_full_size(ife, dev):
+    import torch
+    ctx = dev["ctx"]
+    run(ife, dev, dev["img"], dev["mask"], 4.0, dev["out_a"])
+    ctx.set_option(ife.OPT_ZCHUNK, 37)
+    ctx.set_option(ife.OPT_IIR_BLOCK, 8)
+    try:
+        run(ife, dev, dev["img"], dev["mask"], 4.0, dev["out_b"])
+    finally:
+        ctx.set_option(ife.OPT_ZCHUNK, 64)
+        ctx.set_option(ife.OPT_IIR_BLOCK, 16)
+    assert bool(torch.equal(dev["out_a"], dev["out_b"]))
+
+
+def test_planar_layout_at_full_size(ife, dev):
+    import torch
+    run(ife, dev, dev["img"], dev["mask"], 1.0, dev["out_a"])
+    run(ife, dev, dev["img"], dev["mask"], 1.0, dev["out_b"], ife.PLANAR)
+    pl = dev["out_b"].view(8, N, N, N)
+    for c in range(8):
+        assert bool(torch.equal(pl[c], dev["out_a"][..., c]))
+
+
+def test_unsmoothed_path_crop_matches_oracle(ife, oracle, big, dev):
+    """Config 2 shape (Hessian + eigen features, no smoothing) at 512^3: a crop with a
+    2-voxel margin reproduces the interior exactly on the oracle."""
+    import torch
+    img, mask = big
+    out = dev["out_a"].view(-1)[: N * N * N * 6].view(N, N, N, 6)
+    dev["ctx"].fd_hessian_features_device(dev["img"].data_ptr(), ife.F32, dev["mask"].data_ptr(),
+                                          ife.U8, (N, N, N), (1.0, 1.0, 1.0), out.data_ptr())
+    torch.cuda.synchronize()
+    z0, y0, x0, e = 200, 180, 300, 48
+    sl = (slice(z0 - 2, z0 + e + 2), slice(y0 - 2, y0 + e + 2), slice(x0 - 2, x0 + e + 2))
+    ref = oracle.fd_hessian_features(np.ascontiguousarray(img[sl]),
+                                     np.ascontiguousarray(mask[sl]))[2:-2, 2:-2, 2:-2]
+    got = out[z0:z0 + e, y0:y0 + e, x0:x0 + e].cpu().numpy()
+    lam = np.maximum(np.abs(ref[..., 0]).astype(np.float64), 1e-30)
+    d = np.abs(got.astype(np.float64) - ref)
+    assert (d[..., 0:4] / lam[..., None]).max() <= 1e-6
+    assert (mask[z0:z0 + e, y0:y0 + e, x0:x0 + e] != 0).any()

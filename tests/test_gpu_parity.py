@@ -299,3 +299,25 @@ def test_bad_arguments(ctx, ife):
     assert e.value.code == ife.E_ARG
     with pytest.raises(ife.IfeError):
         ctx.set_option(999, 1)
+
+
+# ---------------------------------------------------------------------------------
+# self-pinned golden files (tests/golden/make_golden.py)
+# ---------------------------------------------------------------------------------
+def test_golden_pipeline_snapshot_on_device(ctx):
+    z = np.load(os.path.join(HERE, "golden", "pipeline_24x20x28.npz"))
+    got = ctx.emphysema_features(z["image"], z["mask"], list(z["sigmas"]), tuple(z["spacing"]))
+    for s in range(len(z["sigmas"])):
+        assert_features_close(got[s], z["features"][s], z["mask"])
+
+
+def test_golden_fd_snapshot_on_device(ctx):
+    z = np.load(os.path.join(HERE, "golden", "fd_hessian_20.npz"))
+    np.testing.assert_array_equal(ctx.hessian3d(z["image"]), z["hessian"])
+    np.testing.assert_array_equal(ctx.gradient_magnitude(z["image"]), z["gradmag"])
+    assert_features_close(ctx.fd_hessian_features(z["image"], z["mask"]), z["features"], z["mask"])
+
+
+def test_golden_eigen_fixture_on_device(ctx):
+    z = np.load(os.path.join(HERE, "golden", "eigen_f32.npz"))
+    assert eig_rel_err(ctx.eigenvalues(z["A"]), z["ev_cmath"]) <= REL_TOL
