@@ -37,6 +37,7 @@ EXPORTS = (
     "ife_normalized_gaussian_convolution", "ife_emphysema_features",
     "ife_fd_hessian_features", "ife_fd_gradient_features", "ife_mask_image_f64",
     "ife_get_kernel_times", "ife_reset_kernel_times",
+    "ife_stage_prepare", "ife_stage_recursive_gaussian", "ife_stage_features",
 )
 
 
@@ -90,6 +91,9 @@ def load_library():
     lib.ife_fd_hessian_features.argtypes = [vp, vp, i32, vp, i32, vd, f32p, i32, i32]
     lib.ife_fd_gradient_features.argtypes = [vp, f32p, f32p, vd, f32p, i32]
     lib.ife_mask_image_f64.argtypes = [vp, vp, vp, C.c_double, i64, vp, i32]
+    lib.ife_stage_prepare.argtypes = [vp, vp, i32, vp, i32, i64, vp, vp]
+    lib.ife_stage_recursive_gaussian.argtypes = [vp, vp, vp, vd, i32, C.c_double]
+    lib.ife_stage_features.argtypes = [vp, vp, vp, vp, i32, vd, i32, i32, vp, i32]
     lib.ife_get_kernel_times.argtypes = [vp, C.POINTER(KernelTime), i32]
     lib.ife_reset_kernel_times.argtypes = [vp]
     _lib = lib
@@ -280,3 +284,23 @@ class Context:
         self._chk(self._lib.ife_fd_hessian_features(
             self._h, C.c_void_p(image_ptr), image_dtype, C.c_void_p(mask_ptr or 0), mask_dtype,
             C.byref(d), C.c_void_p(out_ptr), layout, MEM_DEVICE))
+
+    # ---- stage entry points (device pointers; Z-slab orchestration, slab.py) ------------
+    def stage_prepare(self, image_ptr, image_dtype, mask_ptr, mask_dtype, n, tc_ptr, cf_ptr):
+        self._chk(self._lib.ife_stage_prepare(
+            self._h, C.c_void_p(image_ptr), image_dtype, C.c_void_p(mask_ptr or 0), mask_dtype,
+            int(n), C.c_void_p(tc_ptr), C.c_void_p(cf_ptr or 0)))
+
+    def stage_recursive_gaussian(self, in_ptr, out_ptr, shape_zyx, spacing, axis_xyz, sigma):
+        d = _desc(shape_zyx, spacing)
+        self._chk(self._lib.ife_stage_recursive_gaussian(
+            self._h, C.c_void_p(in_ptr), C.c_void_p(out_ptr), C.byref(d), int(axis_xyz),
+            float(sigma)))
+
+    def stage_features(self, num_ptr, den_ptr, mask_ptr, mask_dtype, slab_shape_zyx, spacing,
+                       halo_lo, halo_hi, out_ptr, layout=INTERLEAVED):
+        d = _desc(slab_shape_zyx, spacing)
+        self._chk(self._lib.ife_stage_features(
+            self._h, C.c_void_p(num_ptr), C.c_void_p(den_ptr or 0), C.c_void_p(mask_ptr or 0),
+            mask_dtype, C.byref(d), int(bool(halo_lo)), int(bool(halo_hi)), C.c_void_p(out_ptr),
+            layout))

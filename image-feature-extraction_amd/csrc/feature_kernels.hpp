@@ -46,6 +46,10 @@ struct FeatGeom {
   int zchunk;
   int64_t plane;  // nx*ny
   int64_t nvox;
+  // Z-slab support: the value buffer may carry one halo plane in front (zoff = 1) and
+  // one behind; value plane of output plane z is clamp(z + zoff, 0, zc_hi).  Whole
+  // volume: zoff = 0, zc_hi = nz - 1 (replicate boundary at both ends).
+  int zoff, zc_hi;
 };
 
 // Operator coefficients after FlipAxes and ScaleCoefficients (double), per axis.
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(FT_THREADS) void features_kernel(VAL val, const TM 
   float r[FT_NLD];
   uint32_t mr = 0;
   auto load_plane = [&](int p) {
-    const int64_t pb = (int64_t)clampi(p, g.nz - 1) * g.plane;
+    const int64_t pb = (int64_t)clampi(p + g.zoff, g.zc_hi) * g.plane;
 #pragma unroll
     for (int k = 0; k < FT_NLD; ++k)
       if (has[k]) r[k] = val.ld(pb + off[k]);

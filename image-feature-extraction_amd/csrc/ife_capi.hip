@@ -338,12 +338,14 @@ int smooth_field(ife_ctx *ctx, SRC src, float *buf_a, float *buf_b, const ife_vo
 
 template <int MODE, typename VAL, typename TM>
 int launch_features(ife_ctx *ctx, VAL val, const TM *mask, float *out,
-                    const ife_volume_desc *v, int layout) {
+                    const ife_volume_desc *v, int layout, int halo_lo = 0, int halo_hi = 0) {
   FeatGeom g;
   g.nx = (int)v->nx; g.ny = (int)v->ny; g.nz = (int)v->nz;
   g.zchunk = ctx->zchunk;
   g.plane = v->nx * v->ny;
   g.nvox = g.plane * v->nz;
+  g.zoff = halo_lo ? 1 : 0;
+  g.zc_hi = (int)v->nz + g.zoff + (halo_hi ? 1 : 0) - 1;
   const DerivCoef dc = deriv_coeffs(v, ctx->dscale_mode);
   dim3 grid((unsigned)((v->nx + FT_TX - 1) / FT_TX), (unsigned)((v->ny + FT_TY - 1) / FT_TY),
             (unsigned)((v->nz + g.zchunk - 1) / g.zchunk));
@@ -758,6 +760,62 @@ int ife_mask_image_f64(ife_ctx *ctx, const double *image, const double *mask, do
     IFE_HIP(ctx, hipGetLastError());
   }
   return stage_out_end(ctx, mem, out, (size_t)n * 8);
+}
+
+// ---- stage entry points (device pointers only; Z-slab orchestration) --------------------
+int ife_stage_prepare(ife_ctx *ctx, const void *image, int image_dtype, const void *mask,
+                      int mask_dtype, int64_t n, float *tc, float *cf) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if (!image || !tc || n <= 0) return fail(ctx, IFE_E_ARG, "null pointer or empty volume");
+  if (image_dtype != IFE_F32 && image_dtype != IFE_I16)
+    return fail(ctx, IFE_E_ARG, "image dtype must be IFE_F32 or IFE_I16");
+  if (mask && mask_dtype != IFE_U8 && mask_dtype != IFE_U16)
+    return fail(ctx, IFE_E_ARG, "mask dtype must be IFE_U8 or IFE_U16");
+  const bool u16 = mask && mask_dtype == IFE_U16;
+  if (image_dtype == IFE_F32)
+    return u16 ? launch_prep(ctx, (const float *)image, (const uint16_t *)mask, tc, cf, n)
+               : launch_prep(ctx, (const float *)image, (const uint8_t *)mask, tc, cf, n);
+  return u16 ? launch_prep(ctx, (const int16_t *)image, (const uint16_t *)mask, tc, cf, n)
+             : launch_prep(ctx, (const int16_t *)image, (const uint8_t *)mask, tc, cf, n);
+}
+
+int ife_stage_recursive_gaussian(ife_ctx *ctx, const float *in, float *out,
+                                 const ife_volume_desc *vol, int axis, double sigma) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_vol(ctx, vol, false))) return rc;
+  if (!in || !out) return fail(ctx, IFE_E_ARG, "null pointer");
+  if (in == out) return fail(ctx, IFE_E_ARG, "the axis pass is not in place");
+  if (axis < 0 || axis > 2) return fail(ctx, IFE_E_ARG, "axis must be 0 (x), 1 (y) or 2 (z)");
+  if (!(sigma > 0.0)) return fail(ctx, IFE_E_ARG, "sigma must be positive");
+  const int64_t len = axis == 0 ? vol->nx : axis == 1 ? vol->ny : vol->nz;
+  if (len < 4)
+    return fail(ctx, IFE_E_SIZE, "the recursive Gaussian needs at least 4 voxels along axis %d",
+                axis);
+  if ((rc = ensure_ck(ctx, vol))) return rc;
+  IirCoef c;
+  const double sp = axis == 0 ? vol->sx : axis == 1 ? vol->sy : vol->sz;
+  if (gauss_coeffs(sigma, sp, &c)) return fail(ctx, IFE_E_ARG, "spacing is suspiciously small");
+  if (axis == 0) return launch_contig(ctx, in, out, vol, c);
+  return launch_strided(ctx, SrcF32{in}, out, vol, axis, c);
+}
+
+int ife_stage_features(ife_ctx *ctx, const float *num, const float *den, const void *mask,
+                       int mask_dtype, const ife_volume_desc *slab, int halo_lo, int halo_hi,
+                       float *out, int layout) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_vol(ctx, slab, false))) return rc;
+  if ((rc = check_layout_mem(ctx, layout, IFE_MEM_DEVICE))) return rc;
+  if (!num || !out) return fail(ctx, IFE_E_ARG, "null pointer");
+  if (mask && mask_dtype != IFE_U8 && mask_dtype != IFE_U16)
+    return fail(ctx, IFE_E_ARG, "mask dtype must be IFE_U8 or IFE_U16");
+  if (mask && mask_dtype == IFE_U16)
+    return launch_features<FEAT_FEATURES8>(ctx, ValSmooth{num, den}, (const uint16_t *)mask, out,
+                                           slab, layout, halo_lo, halo_hi);
+  return launch_features<FEAT_FEATURES8>(ctx, ValSmooth{num, den}, (const uint8_t *)mask, out,
+                                         slab, layout, halo_lo, halo_hi);
 }
 
 // ---- measurement ----------------------------------------------------------------------
