@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--iir-block", type=int, default=None)
     ap.add_argument("--zchunk", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-slab", action="store_true",
+                    help="run the Z-slab engine (RCCL exchanges) even with one rank")
     ap.add_argument("--cpu-sample", type=int, default=384, help="edge of the CPU baseline cube")
     return ap.parse_args()
 
@@ -88,8 +90,10 @@ def main():
                          % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_slab
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = importlib.import_module(PKG)
@@ -99,7 +103,7 @@ def main():
     seed = synth.SEED_CONFIG[3]
     layout = pkg.INTERLEAVED if args.layout == "interleaved" else pkg.PLANAR
 
-    if world > 1:
+    if use_dist:
         slab = importlib.import_module(PKG + ".slab")
         runner = slab.SlabRunner(pkg, synth, (nz, ny, nx), sigmas, seed, args.mask, layout,
                                  rank, world, dev, args)
@@ -108,7 +112,7 @@ def main():
                                  args)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -126,7 +130,7 @@ def main():
     ktimes = runner.ctx.kernel_times()
     runner.ctx.set_option(pkg.OPT_PROFILE, 0)
 
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -177,7 +181,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth, seed, sigmas, args.cpu_sample)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

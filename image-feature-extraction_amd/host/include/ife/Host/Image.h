@@ -1,0 +1,139 @@
+// Image.h -- the few itk:: types the hot-path callers of the reference touch, without ITK.
+//
+// The reference's tools hold images as itk::Image<T,3> / itk::VectorImage<T,3> behind
+// itk::SmartPointer (e.g. tools/ExtractFeatures.cxx:81-96).  ITK is not available in
+// this build, so the host mirror provides these names with the members those callers
+// use; buffers are x-fastest like itk::Image, vector images interleaved like
+// itk::VectorImage.  When real ITK is present the filters are used through the adapter
+// shown in INTEGRATION.md instead and this header is not needed.
+#ifndef IFE_HOST_IMAGE_H
+#define IFE_HOST_IMAGE_H
+
+#include <array>
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace itk {
+
+// itk::ExceptionObject: what the tools catch in main (ExtractFeatures.cxx:145-152)
+class ExceptionObject : public std::runtime_error {
+ public:
+  explicit ExceptionObject(const std::string &what, const std::string &where = "")
+      : std::runtime_error(where.empty() ? what : where + ": " + what) {}
+  const char *GetDescription() const { return what(); }
+};
+inline std::ostream &operator<<(std::ostream &os, const ExceptionObject &e) {
+  return os << "itk::ExceptionObject: " << e.what();
+}
+
+template <typename T>
+class SmartPointer {
+ public:
+  SmartPointer() = default;
+  SmartPointer(std::nullptr_t) {}
+  explicit SmartPointer(T *p) : p_(p) {}
+  SmartPointer(const std::shared_ptr<T> &p) : p_(p) {}
+  template <typename U>
+  SmartPointer(const SmartPointer<U> &o) : p_(o.shared()) {}
+  T *operator->() const { return p_.get(); }
+  T &operator*() const { return *p_; }
+  T *GetPointer() const { return p_.get(); }
+  bool IsNull() const { return !p_; }
+  bool IsNotNull() const { return bool(p_); }
+  operator T *() const { return p_.get(); }
+  const std::shared_ptr<T> &shared() const { return p_; }
+
+ private:
+  std::shared_ptr<T> p_;
+};
+
+#define ifeNewMacro(Self)                              \
+  typedef ::itk::SmartPointer<Self> Pointer;           \
+  typedef ::itk::SmartPointer<const Self> ConstPointer; \
+  static Pointer New() { return Pointer(std::make_shared<Self>()); }
+
+struct Size3 {
+  std::array<uint64_t, 3> v{{0, 0, 0}};
+  uint64_t &operator[](size_t i) { return v[i]; }
+  const uint64_t &operator[](size_t i) const { return v[i]; }
+};
+struct Spacing3 {
+  std::array<double, 3> v{{1.0, 1.0, 1.0}};
+  double &operator[](size_t i) { return v[i]; }
+  const double &operator[](size_t i) const { return v[i]; }
+};
+struct Region3 {
+  Size3 size;
+  const Size3 &GetSize() const { return size; }
+  uint64_t GetNumberOfPixels() const { return size[0] * size[1] * size[2]; }
+};
+
+class ImageBase3 {
+ public:
+  virtual ~ImageBase3() {}
+  void SetRegions(const Size3 &s) { region_.size = s; }
+  const Region3 &GetLargestPossibleRegion() const { return region_; }
+  const Region3 &GetBufferedRegion() const { return region_; }
+  void SetSpacing(const Spacing3 &s) { spacing_ = s; }
+  const Spacing3 &GetSpacing() const { return spacing_; }
+  void SetOrigin(const Spacing3 &o) { origin_ = o; }
+  const Spacing3 &GetOrigin() const { return origin_; }
+  void CopyInformation(const ImageBase3 *o) {
+    region_ = o->region_;
+    spacing_ = o->spacing_;
+    origin_ = o->origin_;
+  }
+
+ protected:
+  Region3 region_;
+  Spacing3 spacing_, origin_;
+};
+
+template <typename TPixel, unsigned int VDim = 3>
+class Image : public ImageBase3 {
+  static_assert(VDim == 3, "the hot path is three-dimensional");
+
+ public:
+  typedef Image Self;
+  typedef TPixel PixelType;
+  static const unsigned int ImageDimension = 3;
+  ifeNewMacro(Self);
+  void Allocate() { buf_.assign(region_.GetNumberOfPixels(), TPixel()); }
+  TPixel *GetBufferPointer() { return buf_.data(); }
+  const TPixel *GetBufferPointer() const { return buf_.data(); }
+  unsigned int GetNumberOfComponentsPerPixel() const { return 1; }
+  std::vector<TPixel> &Buffer() { return buf_; }
+
+ private:
+  std::vector<TPixel> buf_;
+};
+
+template <typename TPixel, unsigned int VDim = 3>
+class VectorImage : public ImageBase3 {
+  static_assert(VDim == 3, "the hot path is three-dimensional");
+
+ public:
+  typedef VectorImage Self;
+  typedef TPixel InternalPixelType;
+  typedef TPixel PixelType;  // component type (the reference uses it as such: .h:38,94)
+  static const unsigned int ImageDimension = 3;
+  ifeNewMacro(Self);
+  void SetNumberOfComponentsPerPixel(unsigned int n) { ncomp_ = n; }
+  unsigned int GetNumberOfComponentsPerPixel() const { return ncomp_; }
+  void Allocate() { buf_.assign(region_.GetNumberOfPixels() * ncomp_, TPixel()); }
+  TPixel *GetBufferPointer() { return buf_.data(); }  // [voxel*ncomp + c]
+  const TPixel *GetBufferPointer() const { return buf_.data(); }
+
+ private:
+  unsigned int ncomp_ = 1;
+  std::vector<TPixel> buf_;
+};
+
+}  // namespace itk
+
+#endif

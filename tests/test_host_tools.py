@@ -1,0 +1,146 @@
+"""The C++ host mirror: tool surface (flags, output names, exit codes) and results.
+
+CPU part: the tools build, print usage, reject bad command lines with EXIT_FAILURE and --
+there being no GPU here -- fail loudly instead of falling back to a CPU path.
+GPU part (-m gpu): the tools produce the reference's output file names and the oracle's
+values; host_selftest exercises the filter classes and functors.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "image-feature-extraction_amd", "host")
+BIN = os.path.join(HOST, "bin")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import niftiio  # noqa: E402
+
+TOOLS = ["ExtractFeatures", "FiniteDifference_HessianFeatures", "FiniteDifference_GradientFeatures",
+         "MaskedNormalizedConvolution", "MaskedImageFilter"]
+
+
+@pytest.fixture(scope="module")
+def built():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "image-feature-extraction_amd", "csrc")])
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    return BIN
+
+
+def run(tool, *args):
+    return subprocess.run([os.path.join(BIN, tool)] + list(args), capture_output=True, text=True)
+
+
+@pytest.mark.parametrize("tool", TOOLS)
+def test_usage_and_argument_errors(built, tool):
+    r = run(tool, "--help")
+    assert r.returncode == 0 and "--image" in r.stdout and "USAGE" in r.stdout
+    r = run(tool)  # required arguments missing: TCLAP-style message, EXIT_FAILURE
+    assert r.returncode == 1 and "Error :" in r.stderr and "for arg" in r.stderr
+    r = run(tool, "--bogus", "1")
+    assert r.returncode == 1 and "Couldn't find match" in r.stderr
+
+
+def test_reference_flag_names(built):
+    assert all(f in run("ExtractFeatures", "--help").stdout for f in ("-i,", "-m,", "-o,", "-s,", "--scale"))
+    h = run("FiniteDifference_HessianFeatures", "--help").stdout
+    assert "--outdir" in h and "--prefix" in h
+    h = run("MaskedNormalizedConvolution", "--help").stdout
+    assert "--certainty" in h and "--maskoutput" in h and "--scale" in h
+    assert "--outside-value" in run("MaskedImageFilter", "--help").stdout
+
+
+def test_no_gpu_means_failure_not_fallback(built, tmp_path, synth):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    img = synth.volume_f32((8, 8, 8), 1)
+    niftiio.write(str(tmp_path / "i.nii"), img)
+    niftiio.write(str(tmp_path / "m.nii"), np.ones((8, 8, 8), np.uint8))
+    r = run("ExtractFeatures", "-i", str(tmp_path / "i.nii"), "-m", str(tmp_path / "m.nii"),
+            "-o", str(tmp_path / "o"), "-s", "1")
+    assert r.returncode == 1
+    assert "Failed to process." in r.stderr and "no CPU path" in r.stderr
+
+
+def test_missing_input_file(built, tmp_path):
+    r = run("MaskedImageFilter", "-i", str(tmp_path / "nope.nii"), "-m", str(tmp_path / "nope.nii"),
+            "-o", str(tmp_path / "o.nii"))
+    assert r.returncode == 1 and "cannot open" in r.stderr
+
+
+@pytest.mark.gpu
+def test_host_selftest(built, tmp_path):
+    r = subprocess.run([os.path.join(BIN, "host_selftest"), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "host_selftest: ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_extract_features_tool(built, tmp_path, synth, oracle):
+    shape, spacing = (20, 24, 28), (0.75, 0.75, 1.5)
+    img = synth.volume_f32(shape, 21)
+    labels = synth.mask_ellipsoids(shape)            # 0/1/2: the tool clamps to {0,1}
+    niftiio.write(str(tmp_path / "img.nii.gz"), img, spacing)
+    niftiio.write(str(tmp_path / "mask.nii.gz"), labels, spacing)
+    r = run("ExtractFeatures", "-i", str(tmp_path / "img.nii.gz"), "-m", str(tmp_path / "mask.nii.gz"),
+            "-o", str(tmp_path / "out"), "-s", "1", "--scale", "2.5")
+    assert r.returncode == 0, r.stderr
+    names = ["GaussianBlur", "GradientMagnitude", "Eigenvalue1", "Eigenvalue2", "Eigenvalue3",
+             "LaplacianOfGaussian", "GaussianCurvature", "FrobeniusNorm"]
+    mask = np.minimum(labels, 1).astype(np.uint8)
+    for sig, tag in ((1.0, "1.000000"), (2.5, "2.500000")):     # std::to_string(float)
+        ref = oracle.emphysema_features(img, mask, sig, spacing)
+        for c, nm in enumerate(names):
+            path = str(tmp_path / ("out_scale_%s%s.nii.gz" % (tag, nm)))
+            assert os.path.exists(path), path
+            vol, sp = niftiio.read(path)
+            assert vol.dtype == np.float32 and np.allclose(sp, spacing)
+            lam = np.maximum(np.abs(ref[..., 2]), 1e-30) ** (3 if c == 6 else 1)
+            if c < 2:
+                np.testing.assert_array_equal(vol, ref[..., c])
+            else:
+                assert (np.abs(vol.astype(np.float64) - ref[..., c]) / lam).max() <= 3e-6
+
+
+@pytest.mark.gpu
+def test_fd_and_mask_tools(built, tmp_path, synth, oracle):
+    shape = (12, 16, 20)
+    img = synth.volume_f32(shape, 22)
+    mask = np.minimum(synth.mask_ellipsoids(shape), 1).astype(np.uint8)
+    niftiio.write(str(tmp_path / "img.nii"), img)
+    niftiio.write(str(tmp_path / "mask.nii"), mask)
+    os.mkdir(str(tmp_path / "o"))
+    env = dict(os.environ, IFE_OUT_FILE_TYPE=".nii")
+    r = subprocess.run([os.path.join(BIN, "FiniteDifference_HessianFeatures"), "-i", str(tmp_path / "img.nii"),
+                        "-m", str(tmp_path / "mask.nii"), "-o", str(tmp_path / "o") + "//"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    ref = oracle.fd_hessian_features(img, mask)
+    for c, nm in enumerate(["eig1", "eig2", "eig3", "LoG", "Curvature", "Frobenius"]):
+        vol, _ = niftiio.read(str(tmp_path / "o" / ("hessian_%s.nii" % nm)))   # default prefix
+        lam = np.maximum(np.abs(ref[..., 0]), 1e-30) ** (3 if c == 4 else 1)
+        assert (np.abs(vol.astype(np.float64) - ref[..., c]) / lam).max() <= 3e-6
+    r = subprocess.run([os.path.join(BIN, "FiniteDifference_GradientFeatures"), "-i", str(tmp_path / "img.nii"),
+                        "-m", str(tmp_path / "mask.nii"), "-o", str(tmp_path / "o"), "-p", "g_"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    vol, _ = niftiio.read(str(tmp_path / "o" / "g_GradientMagnitude.nii"))
+    np.testing.assert_array_equal(vol, oracle.fd_gradient_features(img, mask.astype(np.float32)))
+    # normalized convolution, masked output, double scale
+    r = subprocess.run([os.path.join(BIN, "MaskedNormalizedConvolution"), "-i", str(tmp_path / "img.nii"),
+                        "-c", str(tmp_path / "mask.nii"), "-s", "1.5", "-o", str(tmp_path / "o"),
+                        "-m", "true"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    vol, _ = niftiio.read(str(tmp_path / "o" / "normconv_scale_1.500000.nii"))
+    nc = oracle.normalized_gaussian_convolution(img, mask.astype(np.float32), 1.5)
+    np.testing.assert_array_equal(vol, np.where(mask != 0, nc, 0).astype(np.float32))
+    # MaskedImageFilter: double pixels, outside value
+    r = run("MaskedImageFilter", "-i", str(tmp_path / "img.nii"), "-m", str(tmp_path / "mask.nii"),
+            "-o", str(tmp_path / "masked.nii"), "-v", "-3.5")
+    assert r.returncode == 0, r.stderr
+    vol, _ = niftiio.read(str(tmp_path / "masked.nii"))
+    assert vol.dtype == np.float64
+    np.testing.assert_array_equal(vol, np.where(mask != 0, img.astype(np.float64), -3.5))
