@@ -98,7 +98,7 @@ def test_extract_features_tool(built, tmp_path, synth, oracle):
             assert os.path.exists(path), path
             vol, sp = niftiio.read(path)
             assert vol.dtype == np.float32 and np.allclose(sp, spacing)
-            lam = np.maximum(np.abs(ref[..., 2]), 1e-30) ** (3 if c == 6 else 1)
+            lam = np.maximum(np.abs(ref[..., 2]).astype(np.float64), 1e-30) ** (3 if c == 6 else 1)
             if c < 2:
                 np.testing.assert_array_equal(vol, ref[..., c])
             else:
@@ -121,7 +121,7 @@ def test_fd_and_mask_tools(built, tmp_path, synth, oracle):
     ref = oracle.fd_hessian_features(img, mask)
     for c, nm in enumerate(["eig1", "eig2", "eig3", "LoG", "Curvature", "Frobenius"]):
         vol, _ = niftiio.read(str(tmp_path / "o" / ("hessian_%s.nii" % nm)))   # default prefix
-        lam = np.maximum(np.abs(ref[..., 0]), 1e-30) ** (3 if c == 4 else 1)
+        lam = np.maximum(np.abs(ref[..., 0]).astype(np.float64), 1e-30) ** (3 if c == 4 else 1)
         assert (np.abs(vol.astype(np.float64) - ref[..., c]) / lam).max() <= 3e-6
     r = subprocess.run([os.path.join(BIN, "FiniteDifference_GradientFeatures"), "-i", str(tmp_path / "img.nii"),
                         "-m", str(tmp_path / "mask.nii"), "-o", str(tmp_path / "o"), "-p", "g_"],
