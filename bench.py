@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-slab", action="store_true",
                     help="run the Z-slab engine (RCCL exchanges) even with one rank")
-    ap.add_argument("--cpu-sample", type=int, default=384, help="edge of the CPU baseline cube")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="edge of the CPU baseline cube")
     return ap.parse_args()
 
 

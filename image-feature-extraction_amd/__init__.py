@@ -17,7 +17,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libife_hip.so")
+# IFE_HIP_LIB selects another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("IFE_HIP_LIB") or os.path.join(_HERE, "csrc", "libife_hip.so")
 
 # enums of include/ife_hip.h
 OK, E_ARG, E_SIZE, E_HIP, E_NOMEM, E_STATE = 0, -1, -2, -3, -4, -5

@@ -50,6 +50,7 @@ struct FeatGeom {
   // one behind; value plane of output plane z is clamp(z + zoff, 0, zc_hi).  Whole
   // volume: zoff = 0, zc_hi = nz - 1 (replicate boundary at both ends).
   int zoff, zc_hi;
+  int gx, gy, gz;  // tiles along x, y and z-chunks; the launch grid is 1-D (gx*gy*gz)
 };
 
 // Operator coefficients after FlipAxes and ScaleCoefficients (double), per axis.
@@ -96,7 +97,10 @@ __device__ __forceinline__ float d2(double ca, double cb, double cc, float fm, f
 }
 
 constexpr int FT_TX = 64;
-constexpr int FT_TY = 8;
+#ifndef IFE_FT_TY
+#define IFE_FT_TY 8
+#endif
+constexpr int FT_TY = IFE_FT_TY;
 constexpr int FT_HX = FT_TX + 2;
 constexpr int FT_HY = FT_TY + 2;
 constexpr int FT_NE = FT_HX * FT_HY;  // staged elements per plane (tile + halo)
@@ -117,7 +121,10 @@ constexpr int FT_NLD = (FT_NE + FT_THREADS - 1) / FT_THREADS;  // staged element
 // Both forms are bit-identical to the generic inner products, except that the sign of
 // an exact zero is not tracked (+0/-0 compare equal and never reach a non-zero output).
 template <int MODE, bool UNIT, int TRIG, typename VAL, typename TM>
-__global__ __launch_bounds__(FT_THREADS) void features_kernel(VAL val, const TM *__restrict__ mask,
+#ifndef IFE_FT_WAVES
+#define IFE_FT_WAVES 1
+#endif
+__global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL val, const TM *__restrict__ mask,
                                                               float *__restrict__ out, FeatGeom g,
                                                               DerivCoef dc, int planar) {
   __shared__ float tile[4][FT_HY][FT_HX];
@@ -132,8 +139,24 @@ __global__ __launch_bounds__(FT_THREADS) void features_kernel(VAL val, const TM 
 
   const int tid = threadIdx.x;
   const int tx = tid & 63, ty = tid >> 6;
-  const int x = blockIdx.x * FT_TX + tx, y = blockIdx.y * FT_TY + ty;
-  const int z0 = blockIdx.z * g.zchunk;
+  // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (linear id
+  // % 8 labels the XCD), and neighbouring tiles share halo rows/columns and z-planes, so
+  // each XCD gets one contiguous run of the (z-chunk, tile-row, tile-column) order: the
+  // halo re-reads then hit that XCD's own L2 instead of going to the fabric as whole
+  // 128-B lines.  Placement only affects speed, never results.
+  int bx, by, bz;
+  {
+    const uint32_t nb = (uint32_t)g.gx * (uint32_t)g.gy * (uint32_t)g.gz;
+    const uint32_t lin = blockIdx.x;
+    const uint32_t per = nb / 8u, rem = nb % 8u;  // XCD c owns per (+1 if c < rem) tiles
+    const uint32_t c = lin % 8u, i = lin / 8u;
+    const uint32_t t = c * per + (c < rem ? c : rem) + i;
+    bx = (int)(t % (uint32_t)g.gx);
+    by = (int)((t / (uint32_t)g.gx) % (uint32_t)g.gy);
+    bz = (int)(t / ((uint32_t)g.gx * (uint32_t)g.gy));
+  }
+  const int x = bx * FT_TX + tx, y = by * FT_TY + ty;
+  const int z0 = bz * g.zchunk;
   const int z1 = min(z0 + g.zchunk, g.nz);
   const bool inb = x < g.nx && y < g.ny;
 
@@ -147,16 +170,16 @@ __global__ __launch_bounds__(FT_THREADS) void features_kernel(VAL val, const TM 
     has[k] = e < FT_NE;
     const int ey = has[k] ? e / FT_HX : 0, ex = has[k] ? e % FT_HX : 0;
     eidx[k] = ey * FT_HX + ex;
-    off[k] = (int64_t)clampi(blockIdx.x * FT_TX - 1 + ex, g.nx - 1) +
-             (int64_t)g.nx * clampi(blockIdx.y * FT_TY - 1 + ey, g.ny - 1);
+    off[k] = (int64_t)clampi(bx * FT_TX - 1 + ex, g.nx - 1) +
+             (int64_t)g.nx * clampi(by * FT_TY - 1 + ey, g.ny - 1);
   }
   // mask staging: thread t < MT_DW owns dword (t % MT_DWROW) of tile row (t / MT_DWROW).
   // Vector form needs rows that are dword multiples and a dword-aligned base.
   const bool mvec = mask != nullptr && ((int64_t)g.nx * (int64_t)sizeof(TM)) % 4 == 0 &&
                     (reinterpret_cast<uintptr_t>(mask) & 3) == 0;
   const int mrow = tid / MT_DWROW, mcol = tid % MT_DWROW;
-  const int mx = blockIdx.x * FT_TX + mcol * (4 / (int)sizeof(TM));
-  const int my = blockIdx.y * FT_TY + mrow;
+  const int mx = bx * FT_TX + mcol * (4 / (int)sizeof(TM));
+  const int my = by * FT_TY + mrow;
   const bool mine = mvec && tid < MT_DW && mx < g.nx && my < g.ny;
   const int64_t moff = (int64_t)mx + (int64_t)g.nx * my;  // element offset inside a plane
 

@@ -347,10 +347,12 @@ int launch_features(ife_ctx *ctx, VAL val, const TM *mask, float *out,
   g.zoff = halo_lo ? 1 : 0;
   g.zc_hi = (int)v->nz + g.zoff + (halo_hi ? 1 : 0) - 1;
   const DerivCoef dc = deriv_coeffs(v, ctx->dscale_mode);
-  dim3 grid((unsigned)((v->nx + FT_TX - 1) / FT_TX), (unsigned)((v->ny + FT_TY - 1) / FT_TY),
-            (unsigned)((v->nz + g.zchunk - 1) / g.zchunk));
-  if (grid.y > 65535u || grid.z > 65535u)
-    return fail(ctx, IFE_E_SIZE, "volume too large for the feature kernel grid");
+  g.gx = (int)((v->nx + FT_TX - 1) / FT_TX);
+  g.gy = (int)((v->ny + FT_TY - 1) / FT_TY);
+  g.gz = (int)((v->nz + g.zchunk - 1) / g.zchunk);
+  const int64_t nblocks = (int64_t)g.gx * g.gy * g.gz;
+  if (nblocks > 0x7fffffff) return fail(ctx, IFE_E_SIZE, "volume too large for the feature kernel grid");
+  dim3 grid((unsigned)nblocks, 1, 1);
   ProfScope ps(ctx, KK_FEATURES);
   const bool unit = v->sx == 1.0 && v->sy == 1.0 && v->sz == 1.0;
   const int planar = layout == IFE_PLANAR ? 1 : 0;

@@ -349,11 +349,14 @@ __global__ __launch_bounds__(256) void iir_strided_kernel(SRC src, float *__rest
 }
 
 // =================================================================================
-// contiguous axis (X): 64 lines x K samples staged through LDS per wave
+// contiguous axis (X): 64 lines x 2K samples staged through LDS per wave
 // =================================================================================
-template <int K>
+// A tile is two register blocks wide (2K = 32 samples = 128 B per line), so every global
+// access of a line is one whole 128-B cache line; with K-wide tiles each line was
+// fetched twice (PMC: 46 % over-fetch on the X pass).
+template <int W>
 struct XTile {
-  static constexpr int PITCH = K + 4;  // floats; keeps rows 16-B aligned, conflict-free b128 reads
+  static constexpr int PITCH = W + 4;  // floats; keeps rows 16-B aligned, conflict-free b128 reads
   static constexpr int FLOATS = 64 * PITCH;
 };
 
@@ -366,16 +369,16 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// Load samples [i0, i0+K) of the wave's 64 lines into xb (lane = line).
-// `rows` points at sample 0 of the wave's first line (uniform); pitch is the line pitch.
-template <int K>
-__device__ __forceinline__ void xtile_load(const float *rows, float *tile, uint32_t lane,
+// Fill the wave's LDS tile with samples [i0, i0+W) of its 64 lines.  Samples past the
+// line end repeat x[n-1].  `rows` points at sample 0 of the wave's first line (uniform).
+template <int W>
+__device__ __forceinline__ void xtile_fill(const float *rows, float *tile, uint32_t lane,
                                            int64_t nrows, int64_t pitch, int64_t i0, int64_t n,
-                                           bool vec_ok, float (&xb)[K]) {
-  constexpr int P = XTile<K>::PITCH;
-  constexpr int V = K / 4;     // float4 per line-block
+                                           bool vec_ok) {
+  constexpr int P = XTile<W>::PITCH;
+  constexpr int V = W / 4;     // float4 per line
   constexpr int LPI = 64 / V;  // lines covered per wave instruction
-  if (vec_ok && i0 + K <= n) {
+  if (vec_ok && i0 + W <= n) {
     const rsrc_t r4 = make_rsrc(rows + i0);
     u32x4 v[V];
 #pragma unroll
@@ -390,10 +393,10 @@ __device__ __forceinline__ void xtile_load(const float *rows, float *tile, uint3
       *reinterpret_cast<u32x4 *>(tile + ((lane / V) + r * LPI) * P + 4 * (lane % V)) = v[r];
   } else {
 #pragma unroll
-    for (int e = 0; e < K; ++e) {
+    for (int e = 0; e < W; ++e) {
       const uint32_t idx = e * 64 + lane;
-      uint32_t row = idx / K;
-      const uint32_t col = idx % K;
+      uint32_t row = idx / W;
+      const uint32_t col = idx % W;
       const uint32_t trow = row;
       if ((int64_t)row >= nrows) row = (uint32_t)(nrows - 1);
       int64_t i = i0 + col;
@@ -402,27 +405,37 @@ __device__ __forceinline__ void xtile_load(const float *rows, float *tile, uint3
     }
   }
   wave_lds_sync();
-#pragma unroll
-  for (int q = 0; q < V; ++q) {
-    const float4 t = *reinterpret_cast<const float4 *>(tile + lane * P + 4 * q);
-    xb[4 * q + 0] = t.x; xb[4 * q + 1] = t.y; xb[4 * q + 2] = t.z; xb[4 * q + 3] = t.w;
-  }
-  wave_lds_sync();
 }
 
-template <int K>
-__device__ __forceinline__ void xtile_store(float *rows, float *tile, uint32_t lane,
-                                            int64_t nrows, int64_t pitch, int64_t i0, int64_t n,
-                                            bool vec_ok, const float (&ob)[K]) {
-  constexpr int P = XTile<K>::PITCH;
-  constexpr int V = K / 4;
-  constexpr int LPI = 64 / V;
+// Register block h (K samples) of the lane's own line, out of / back into the tile.
+template <int W, int K>
+__device__ __forceinline__ void xtile_get(const float *tile, uint32_t lane, int h, float (&xb)[K]) {
+  constexpr int P = XTile<W>::PITCH;
 #pragma unroll
-  for (int q = 0; q < V; ++q)
-    *reinterpret_cast<float4 *>(tile + lane * P + 4 * q) =
-        make_float4(ob[4 * q + 0], ob[4 * q + 1], ob[4 * q + 2], ob[4 * q + 3]);
+  for (int q = 0; q < K / 4; ++q) {
+    const float4 t = *reinterpret_cast<const float4 *>(tile + lane * P + h * K + 4 * q);
+    xb[4 * q + 0] = t.x; xb[4 * q + 1] = t.y; xb[4 * q + 2] = t.z; xb[4 * q + 3] = t.w;
+  }
+}
+template <int W, int K>
+__device__ __forceinline__ void xtile_put(float *tile, uint32_t lane, int h, const float (&xb)[K]) {
+  constexpr int P = XTile<W>::PITCH;
+#pragma unroll
+  for (int q = 0; q < K / 4; ++q)
+    *reinterpret_cast<float4 *>(tile + lane * P + h * K + 4 * q) =
+        make_float4(xb[4 * q + 0], xb[4 * q + 1], xb[4 * q + 2], xb[4 * q + 3]);
+}
+
+// Write the tile back to samples [i0, i0+W) of the lines (valid samples only).
+template <int W>
+__device__ __forceinline__ void xtile_drain(float *rows, float *tile, uint32_t lane,
+                                            int64_t nrows, int64_t pitch, int64_t i0, int64_t n,
+                                            bool vec_ok) {
+  constexpr int P = XTile<W>::PITCH;
+  constexpr int V = W / 4;
+  constexpr int LPI = 64 / V;
   wave_lds_sync();
-  if (vec_ok && i0 + K <= n) {
+  if (vec_ok && i0 + W <= n) {
     const rsrc_t r4 = make_rsrc(rows + i0);
 #pragma unroll
     for (int r = 0; r < V; ++r) {
@@ -433,9 +446,9 @@ __device__ __forceinline__ void xtile_store(float *rows, float *tile, uint32_t l
     }
   } else {
 #pragma unroll
-    for (int e = 0; e < K; ++e) {
+    for (int e = 0; e < W; ++e) {
       const uint32_t idx = e * 64 + lane;
-      const uint32_t row = idx / K, col = idx % K;
+      const uint32_t row = idx / W, col = idx % W;
       const int64_t i = i0 + col;
       if ((int64_t)row < nrows && i < n) rows[(int64_t)row * pitch + i] = tile[row * P + col];
     }
@@ -444,18 +457,20 @@ __device__ __forceinline__ void xtile_store(float *rows, float *tile, uint32_t l
 }
 
 template <int K>
-__global__ __launch_bounds__(256) void iir_contig_kernel(const float *__restrict__ in,
+__global__ __launch_bounds__(256, 2) void iir_contig_kernel(const float *__restrict__ in,
                                                          float *__restrict__ out, IirGeom g,
                                                          IirCoef c, Checkpoint ck) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * XTile<K>::FLOATS];
+  constexpr int W = 2 * K;  // tile width: two register blocks
+  __shared__ __attribute__((aligned(16))) float lds[4 * XTile<W>::FLOATS];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float *tile = lds + wave * XTile<K>::FLOATS;
+  float *tile = lds + wave * XTile<W>::FLOATS;
   const int64_t line0 = uniform64(((int64_t)blockIdx.x * 4 + wave) * 64);
   if (line0 >= g.nlines) return;
   const int64_t n = g.n, nl = g.nlines, pitch = g.outer;
   const int64_t nrows = nl - line0 < 64 ? nl - line0 : 64;  // live lines of this wave
   const int64_t nb = (n + K - 1) / K;
+  const int64_t nt = (n + W - 1) / W;
   // 16-B accesses need aligned rows; the per-lane byte offset must fit 32 bits
   const bool vec_ok = (pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
@@ -466,50 +481,64 @@ __global__ __launch_bounds__(256) void iir_contig_kernel(const float *__restrict
 
   float xb[K];
 
-  // ---------------- forward sweep ----------------
+  // ---------------- forward sweep: after block b (b <= nb-2) store checkpoint b+1 -------
   {
     CausalState s;
-    for (int64_t b = 0; b + 1 < nb; ++b) {
-      const int64_t i0 = b * K;
-      xtile_load<K>(rows_in, tile, lane, nrows, pitch, i0, n, vec_ok, xb);
-      if (b > 0) {
-        if (live) ck_store(ck, b, nl, line0, lane, s);
+    for (int64_t t = 0; t < nt && 2 * t + 1 < nb; ++t) {
+      xtile_fill<W>(rows_in, tile, lane, nrows, pitch, t * W, n, vec_ok);
+#pragma clang loop unroll(disable)
+      for (int h = 0; h < 2; ++h) {
+        const int64_t b = 2 * t + h;
+        if (b + 1 < nb) {
+          xtile_get<W, K>(tile, lane, h, xb);
+          if (b > 0) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) causal_step(s, (double)xb[j], c);
-      } else {
-        const double x0 = (double)xb[0];
-        s.x1 = s.x2 = s.x3 = x0;
-        s.y1 = s.y2 = s.y3 = s.y4 = x0;
+            for (int j = 0; j < K; ++j) causal_step(s, (double)xb[j], c);
+          } else {
+            const double x0 = (double)xb[0];
+            s.x1 = s.x2 = s.x3 = x0;
+            s.y1 = s.y2 = s.y3 = s.y4 = x0;
 #pragma unroll
-        for (int j = 0; j < K; ++j) causal_step_edge(s, (double)xb[j], c, j);
+            for (int j = 0; j < K; ++j) causal_step_edge(s, (double)xb[j], c, j);
+          }
+          if (live) ck_store(ck, b + 1, nl, line0, lane, s);
+        }
       }
+      wave_lds_sync();  // reads of this tile are done before the next fill overwrites it
     }
-    if (nb > 1 && live) ck_store(ck, nb - 1, nl, line0, lane, s);
   }
 
   // ---------------- backward sweep ----------------
   {
     AntiState a;
-    for (int64_t b = nb - 1; b >= 0; --b) {
-      const int64_t i0 = b * K;
-      xtile_load<K>(rows_in, tile, lane, nrows, pitch, i0, n, vec_ok, xb);
-      if (b == nb - 1) {
-        // x[n-1]: the clamped tile load makes every slot past the line end hold it
-        const double xN = (double)xb[K - 1];
+    for (int64_t t = nt - 1; t >= 0; --t) {
+      xtile_fill<W>(rows_in, tile, lane, nrows, pitch, t * W, n, vec_ok);
+      if (t == nt - 1) {
+        // x[n-1]: the clamped fill makes every slot past the line end hold it
+        const double xN = (double)tile[lane * XTile<W>::PITCH + W - 1];
         a.x1 = a.x2 = a.x3 = a.x4 = xN;
         a.y1 = a.y2 = a.y3 = a.y4 = xN;
       }
-      CausalState s;
-      if (b > 0) {
-        ck_load(ck, b, nl, line0, live ? lane : 0u, s);
-      } else {
-        const double x0 = (double)xb[0];
-        s.x1 = s.x2 = s.x3 = x0;
-        s.y1 = s.y2 = s.y3 = s.y4 = x0;
+#pragma clang loop unroll(disable)
+      for (int h = 1; h >= 0; --h) {
+        const int64_t b = 2 * t + h;
+        if (b < nb) {
+          const int64_t i0 = b * K;
+          xtile_get<W, K>(tile, lane, h, xb);
+          CausalState s;
+          if (b > 0) {
+            ck_load(ck, b, nl, line0, live ? lane : 0u, s);
+          } else {
+            const double x0 = (double)xb[0];
+            s.x1 = s.x2 = s.x3 = x0;
+            s.y1 = s.y2 = s.y3 = s.y4 = x0;
+          }
+          const bool edge = (b == 0) || (i0 + K + 4 > n);
+          backward_block<K>(xb, s, a, c, i0, n, edge);
+          xtile_put<W, K>(tile, lane, h, xb);
+        }
       }
-      const bool edge = (b == 0) || (i0 + K + 4 > n);
-      backward_block<K>(xb, s, a, c, i0, n, edge);
-      xtile_store<K>(rows_out, tile, lane, nrows, pitch, i0, n, vec_ok, xb);
+      xtile_drain<W>(rows_out, tile, lane, nrows, pitch, t * W, n, vec_ok);
     }
   }
 }
