@@ -243,16 +243,16 @@ IirGeom geom_for_axis(const ife_volume_desc *v, int axis) {
   return g;
 }
 
-size_t ck_blocks(int64_t n, int K) { return (size_t)((n + K - 1) / K); }
+size_t ck_pairs(int64_t n, int K) { return (size_t)((n + 2 * K - 1) / (2 * K)); }
 
 int ensure_ck(ife_ctx *ctx, const ife_volume_desc *v) {
   const int K = ctx->iir_block;
   size_t need_y = 0, need_x = 0;
   for (int a = 0; a < 3; ++a) {
     IirGeom g = geom_for_axis(v, a);
-    const size_t nb = ck_blocks(g.n, K);
-    need_y = std::max(need_y, nb * 4 * (size_t)g.nlines * sizeof(double));
-    need_x = std::max(need_x, nb * 3 * (size_t)g.nlines * sizeof(float));
+    const size_t np = ck_pairs(g.n, K);
+    need_y = std::max(need_y, np * 4 * (size_t)g.nlines * sizeof(double));
+    need_x = std::max(need_x, np * 3 * (size_t)g.nlines * sizeof(float));
   }
   int rc = ensure(ctx, ctx->ck_y, need_y);
   if (rc) return rc;
@@ -266,7 +266,7 @@ int launch_strided(ife_ctx *ctx, SRC src, float *out, const ife_volume_desc *v, 
   Checkpoint ck{(double *)ctx->ck_y.p, (float *)ctx->ck_x.p};
   const unsigned blocks = (unsigned)((g.nlines + 255) / 256);
   // 32-bit offsets of the buffer accesses (iir_kernels.hpp "addressing")
-  if ((int64_t)ctx->iir_block * g.sstride * 4 >= (int64_t)1 << 31 ||
+  if ((int64_t)2 * ctx->iir_block * g.sstride * 4 >= (int64_t)1 << 31 ||
       g.outer * 4 >= (int64_t)1 << 32 || g.nlines * 8 * 3 >= (int64_t)1 << 32)
     return fail(ctx, IFE_E_SIZE, "volume too large for the 32-bit offsets of the line kernels");
   ProfScope ps(ctx, axis == 2 ? KK_IIR_Z : KK_IIR_Y);

@@ -188,65 +188,98 @@ struct SrcMul {
 };
 using SrcMulF = SrcMul<float, float>;
 struct Checkpoint {
-  double *y;  // [nblocks][4][nlines]
-  float *x;   // [nblocks][3][nlines]
+  double *y;  // [npairs][4][nlines]: y[i-1..i-4] at the start of every second block
+  float *x;   // [npairs][3][nlines]: x[i-1..i-3], contiguous-axis kernel only
 };
 
-__device__ __forceinline__ void ck_store(const Checkpoint &ck, int64_t b, int64_t nl, int64_t Lw,
-                                         uint32_t lane, const CausalState &s) {
-  const rsrc_t ry = make_rsrc(ck.y + (b * 4) * nl + Lw);
-  const rsrc_t rx = make_rsrc(ck.x + (b * 3) * nl + Lw);
-  const uint32_t sy = (uint32_t)nl * 8u, sx = (uint32_t)nl * 4u;
+// The recursion state is saved once per PAIR of register blocks (every 2K samples); the
+// three input samples in front of the pair are re-read from the input (they sit in rows
+// the sweep loads anyway).  That is 32 B per line per 32 samples each way.
+__device__ __forceinline__ void ck_store(const Checkpoint &ck, int64_t pair, int64_t nl,
+                                         int64_t Lw, uint32_t lane, const CausalState &s) {
+  const rsrc_t ry = make_rsrc(ck.y + (pair * 4) * nl + Lw);
+  const uint32_t sy = (uint32_t)nl * 8u;
   buf_st_f64(ry, lane * 8u, 0u, s.y1);
   buf_st_f64(ry, lane * 8u, sy, s.y2);
   buf_st_f64(ry, lane * 8u, 2u * sy, s.y3);
   buf_st_f64(ry, lane * 8u, 3u * sy, s.y4);
-  buf_st_f32(rx, lane * 4u, 0u, (float)s.x1);
-  buf_st_f32(rx, lane * 4u, sx, (float)s.x2);
-  buf_st_f32(rx, lane * 4u, 2u * sx, (float)s.x3);
 }
-__device__ __forceinline__ void ck_load(const Checkpoint &ck, int64_t b, int64_t nl, int64_t Lw,
-                                        uint32_t lane, CausalState &s) {
-  const rsrc_t ry = make_rsrc(ck.y + (b * 4) * nl + Lw);
-  const rsrc_t rx = make_rsrc(ck.x + (b * 3) * nl + Lw);
-  const uint32_t sy = (uint32_t)nl * 8u, sx = (uint32_t)nl * 4u;
+__device__ __forceinline__ void ck_load(const Checkpoint &ck, int64_t pair, int64_t nl,
+                                        int64_t Lw, uint32_t lane, CausalState &s) {
+  const rsrc_t ry = make_rsrc(ck.y + (pair * 4) * nl + Lw);
+  const uint32_t sy = (uint32_t)nl * 8u;
   s.y1 = buf_ld_f64(ry, lane * 8u, 0u);
   s.y2 = buf_ld_f64(ry, lane * 8u, sy);
   s.y3 = buf_ld_f64(ry, lane * 8u, 2u * sy);
   s.y4 = buf_ld_f64(ry, lane * 8u, 3u * sy);
+}
+
+// The contiguous-axis kernel cannot re-read the x history cheaply (it would be 64
+// scattered 4-B loads per wave), so it keeps it beside the state: 12 B per line per pair.
+__device__ __forceinline__ void ck_store_x(const Checkpoint &ck, int64_t pair, int64_t nl,
+                                           int64_t Lw, uint32_t lane, const CausalState &s) {
+  const rsrc_t rx = make_rsrc(ck.x + (pair * 3) * nl + Lw);
+  const uint32_t sx = (uint32_t)nl * 4u;
+  buf_st_f32(rx, lane * 4u, 0u, (float)s.x1);
+  buf_st_f32(rx, lane * 4u, sx, (float)s.x2);
+  buf_st_f32(rx, lane * 4u, 2u * sx, (float)s.x3);
+}
+__device__ __forceinline__ void ck_load_x(const Checkpoint &ck, int64_t pair, int64_t nl,
+                                          int64_t Lw, uint32_t lane, CausalState &s) {
+  const rsrc_t rx = make_rsrc(ck.x + (pair * 3) * nl + Lw);
+  const uint32_t sx = (uint32_t)nl * 4u;
   s.x1 = (double)buf_ld_f32(rx, lane * 4u, 0u);
   s.x2 = (double)buf_ld_f32(rx, lane * 4u, sx);
   s.x3 = (double)buf_ld_f32(rx, lane * 4u, 2u * sx);
 }
 
-// One register block of the backward sweep: recompute the K causal values from the
-// block's start state, run the anticausal recursion over the same samples and leave
-// float(causal + anticausal) in xb.  `edge` blocks (the first one and those within 4
-// samples of the line end) take the border forms and skip samples >= n.
-template <int K>
-__device__ __forceinline__ void backward_block(float (&xb)[K], CausalState &s, AntiState &a,
-                                               const IirCoef &c, int64_t i0, int64_t n,
-                                               bool edge) {
-  double cz[K];
+// The first block of a pair is run twice from the same state (once to reach the second
+// block, once for its own values).  Left alone, the compiler merges the two runs and keeps
+// all K values of the first one alive across the second block: exactly the register
+// footprint the recomputation is there to avoid.  Passing the state through an empty asm
+// makes the second run opaque.
+__device__ __forceinline__ void opaque_state(CausalState &s) {
+  asm volatile("" : "+v"(s.y1), "+v"(s.y2), "+v"(s.y3), "+v"(s.y4));
+}
+
+// Causal recursion over one register block starting at sample i0.  `edge` blocks (the
+// first one, and any block that may run past the line end) take the border form and skip
+// samples >= n.  STORE keeps the K values for the anticausal pass.
+template <int K, bool STORE>
+__device__ __forceinline__ void causal_run(CausalState &s, const float (&x)[K], double (&cz)[K],
+                                           const IirCoef &c, int64_t i0, int64_t n, bool edge) {
   if (!edge) {
 #pragma unroll
-    for (int j = 0; j < K; ++j) cz[j] = causal_step(s, (double)xb[j], c);
-#pragma unroll
-    for (int j = K - 1; j >= 0; --j) {
-      const double y = anti_step(a, (double)xb[j], c);
-      xb[j] = (float)(cz[j] + y);
+    for (int j = 0; j < K; ++j) {
+      const double y = causal_step(s, (double)x[j], c);
+      if (STORE) cz[j] = y;
     }
   } else {
 #pragma unroll
     for (int j = 0; j < K; ++j)
-      if (i0 + j < n) cz[j] = causal_step_edge(s, (double)xb[j], c, i0 + j);
+      if (i0 + j < n) {
+        const double y = causal_step_edge(s, (double)x[j], c, i0 + j);
+        if (STORE) cz[j] = y;
+      }
+  }
+}
+// Anticausal recursion over the same block, leaving float(causal + anticausal) in x.
+template <int K>
+__device__ __forceinline__ void anti_run(AntiState &a, float (&x)[K], const double (&cz)[K],
+                                         const IirCoef &c, int64_t i0, int64_t n, bool edge) {
+  if (!edge) {
 #pragma unroll
     for (int j = K - 1; j >= 0; --j) {
-      if (i0 + j < n) {
-        const double y = anti_step_edge(a, (double)xb[j], c, i0 + j, n);
-        xb[j] = (float)(cz[j] + y);
-      }
+      const double y = anti_step(a, (double)x[j], c);
+      x[j] = (float)(cz[j] + y);
     }
+  } else {
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j)
+      if (i0 + j < n) {
+        const double y = anti_step_edge(a, (double)x[j], c, i0 + j, n);
+        x[j] = (float)(cz[j] + y);
+      }
   }
 }
 
@@ -267,28 +300,28 @@ __global__ __launch_bounds__(256) void iir_strided_kernel(SRC src, float *__rest
   const int64_t base = (L % g.inner) + (L / g.inner) * g.outer;
   const int64_t wbase = uniform64(base);          // lane 0 of the wave
   const uint32_t voff = (uint32_t)(base - wbase);  // elements (one row jump at most)
-  const uint32_t sst = (uint32_t)st;               // K*st*4 < 2^31 is checked on the host
-  const int64_t nb = (n + K - 1) / K;
+  const uint32_t sst = (uint32_t)st;               // 2K*st*4 < 2^31 is checked on the host
+  const int64_t nb = (n + K - 1) / K;               // register blocks
+  const int64_t np = (nb + 1) / 2;                  // block pairs (checkpoint granularity)
 
-  float xb[K], xn[K];
-
-  // ---------------- forward sweep: checkpoints only ----------------
+  // ---------------- forward sweep: a checkpoint in front of every pair >= 1 ----------------
   {
+    float xb[K], xn[K];
     CausalState s;
-    if (nb > 1) {
+    const int64_t last = 2 * (np - 1);  // first block of the last pair: nothing needed beyond
+    if (last > 0) {
       const auto B = src.at(wbase);
 #pragma unroll
       for (int j = 0; j < K; ++j) xb[j] = src.ld(B, voff, (uint32_t)j * sst);
     }
-    for (int64_t b = 0; b + 1 < nb; ++b) {
+    for (int64_t b = 0; b < last; ++b) {
       const int64_t i0 = b * K;
-      if (b + 2 < nb) {  // prefetch the next full block
+      if (b + 1 < last) {  // prefetch the next (full) block
         const auto B = src.at(wbase + (i0 + K) * st);
 #pragma unroll
         for (int j = 0; j < K; ++j) xn[j] = src.ld(B, voff, (uint32_t)j * sst);
       }
       if (b > 0) {
-        if (live) ck_store(ck, b, nl, Lw, lane, s);
 #pragma unroll
         for (int j = 0; j < K; ++j) causal_step(s, (double)xb[j], c);
       } else {
@@ -298,52 +331,96 @@ __global__ __launch_bounds__(256) void iir_strided_kernel(SRC src, float *__rest
 #pragma unroll
         for (int j = 0; j < K; ++j) causal_step_edge(s, (double)xb[j], c, j);
       }
+      if ((b & 1) && live) ck_store(ck, (b + 1) / 2, nl, Lw, lane, s);
 #pragma unroll
       for (int j = 0; j < K; ++j) xb[j] = xn[j];
     }
-    if (nb > 1 && live) ck_store(ck, nb - 1, nl, Lw, lane, s);
   }
 
-  // ---------------- backward sweep ----------------
+  // ---------------- backward sweep, one pair of blocks per iteration ----------------
   {
+    float xa[K], xb[K];  // blocks 2p and 2p+1 of the current pair
+    float na[K], nb2[K];  // the next pair (p-1), in flight
+    float h1 = 0.f, h2 = 0.f, h3 = 0.f;     // x[i-1..i-3] in front of the current pair
+    float nh1 = 0.f, nh2 = 0.f, nh3 = 0.f;  // the same for the next pair
     AntiState a;
-    {
-      const int64_t i0 = (nb - 1) * K;
+    auto load_pair = [&](int64_t p, float (&pa)[K], float (&pb)[K], bool clampn) {
+      const int64_t i0 = 2 * p * K;
       const auto B = src.at(wbase + i0 * st);
-      const uint32_t last = (uint32_t)(n - 1 - i0);  // 0..K-1
+      if (!clampn) {
 #pragma unroll
-      for (int j = 0; j < K; ++j)
-        xb[j] = src.ld(B, voff, ((uint32_t)j < last ? (uint32_t)j : last) * sst);
-      // x[n-1]: the clamped loads make every slot >= last hold it
+        for (int j = 0; j < K; ++j) pa[j] = src.ld(B, voff, (uint32_t)j * sst);
+#pragma unroll
+        for (int j = 0; j < K; ++j) pb[j] = src.ld(B, voff, (uint32_t)(K + j) * sst);
+      } else {
+        const uint32_t lastj = (uint32_t)(n - 1 - i0);  // 0 .. 2K-1
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+          pa[j] = src.ld(B, voff, ((uint32_t)j < lastj ? (uint32_t)j : lastj) * sst);
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+          pb[j] = src.ld(B, voff, ((uint32_t)(K + j) < lastj ? (uint32_t)(K + j) : lastj) * sst);
+      }
+    };
+    auto load_hist = [&](int64_t p, float &q1, float &q2, float &q3) {
+      const auto B = src.at(wbase + (2 * p * K - 3) * st);  // p >= 1
+      q3 = src.ld(B, voff, 0u);
+      q2 = src.ld(B, voff, sst);
+      q1 = src.ld(B, voff, 2u * sst);
+    };
+    load_pair(np - 1, xa, xb, true);
+    if (np > 1) load_hist(np - 1, h1, h2, h3);
+    {
+      // x[n-1]: the clamped loads make every slot past the line end hold it
       const double xN = (double)xb[K - 1];
       a.x1 = a.x2 = a.x3 = a.x4 = xN;
       a.y1 = a.y2 = a.y3 = a.y4 = xN;
     }
-    for (int64_t b = nb - 1; b >= 0; --b) {
-      const int64_t i0 = b * K;
-      if (b > 0) {
-        const auto B = src.at(wbase + (i0 - K) * st);
-#pragma unroll
-        for (int j = 0; j < K; ++j) xn[j] = src.ld(B, voff, (uint32_t)j * sst);
+    for (int64_t p = np - 1; p >= 0; --p) {
+      const int64_t i0 = 2 * p * K, i1 = i0 + K;
+      if (p > 0) {
+        load_pair(p - 1, na, nb2, false);
+        if (p > 1) load_hist(p - 1, nh1, nh2, nh3);
       }
-      CausalState s;
-      if (b > 0) {
-        ck_load(ck, b, nl, Lw, live ? lane : 0u, s);
+      CausalState s0;
+      if (p > 0) {
+        ck_load(ck, p, nl, Lw, live ? lane : 0u, s0);
+        s0.x1 = (double)h1; s0.x2 = (double)h2; s0.x3 = (double)h3;
       } else {
-        const double x0 = (double)xb[0];
-        s.x1 = s.x2 = s.x3 = x0;
-        s.y1 = s.y2 = s.y3 = s.y4 = x0;
+        const double x0 = (double)xa[0];
+        s0.x1 = s0.x2 = s0.x3 = x0;
+        s0.y1 = s0.y2 = s0.y3 = s0.y4 = x0;
       }
-      const bool edge = (b == 0) || (i0 + K + 4 > n);
-      backward_block<K>(xb, s, a, c, i0, n, edge);
-      if (live) {
-        const rsrc_t ro = make_rsrc(out + wbase + i0 * st);
+      const bool head = p == 0;                 // border form at the line start
+      const bool tail = i1 + K + 4 > n;         // second block touches the last 4 samples
+      const rsrc_t ro = make_rsrc(out + wbase + i0 * st);
+      double cz[K];
+      if (i1 < n) {  // second block of the pair exists: run through the first to reach it
+        CausalState s = s0;
+        causal_run<K, false>(s, xa, cz, c, i0, n, head);
+        causal_run<K, true>(s, xb, cz, c, i1, n, tail);
+        anti_run<K>(a, xb, cz, c, i1, n, tail);
+        if (live) {
 #pragma unroll
-        for (int j = 0; j < K; ++j)
-          if (!edge || i0 + j < n) buf_st_f32(ro, voff * 4u, (uint32_t)j * sst * 4u, xb[j]);
+          for (int j = 0; j < K; ++j)
+            if (!tail || i1 + j < n) buf_st_f32(ro, voff * 4u, (uint32_t)(K + j) * sst * 4u, xb[j]);
+        }
+      }
+      {
+        const bool edge = head || (i0 + K + 4 > n);
+        CausalState s = s0;
+        opaque_state(s);
+        causal_run<K, true>(s, xa, cz, c, i0, n, edge);
+        anti_run<K>(a, xa, cz, c, i0, n, edge);
+        if (live) {
+#pragma unroll
+          for (int j = 0; j < K; ++j)
+            if (!edge || i0 + j < n) buf_st_f32(ro, voff * 4u, (uint32_t)j * sst * 4u, xa[j]);
+        }
       }
 #pragma unroll
-      for (int j = 0; j < K; ++j) xb[j] = xn[j];
+      for (int j = 0; j < K; ++j) { xa[j] = na[j]; xb[j] = nb2[j]; }
+      h1 = nh1; h2 = nh2; h3 = nh3;
     }
   }
 }
@@ -391,8 +468,8 @@ __device__ __forceinline__ void xtile_fill(const float *rows, float *tile, uint3
 #pragma unroll
     for (int r = 0; r < V; ++r)
       *reinterpret_cast<u32x4 *>(tile + ((lane / V) + r * LPI) * P + 4 * (lane % V)) = v[r];
-  } else {
-#pragma unroll
+  } else {  // unaligned or ragged tile: rolled loop (rare path, keep its footprint small)
+#pragma clang loop unroll(disable)
     for (int e = 0; e < W; ++e) {
       const uint32_t idx = e * 64 + lane;
       uint32_t row = idx / W;
@@ -445,7 +522,7 @@ __device__ __forceinline__ void xtile_drain(float *rows, float *tile, uint32_t l
       if ((int64_t)row < nrows) __builtin_amdgcn_raw_buffer_store_b128(v, r4, off, 0u, 0);
     }
   } else {
-#pragma unroll
+#pragma clang loop unroll(disable)
     for (int e = 0; e < W; ++e) {
       const uint32_t idx = e * 64 + lane;
       const uint32_t row = idx / W, col = idx % W;
@@ -469,7 +546,6 @@ __global__ __launch_bounds__(256, 2) void iir_contig_kernel(const float *__restr
   if (line0 >= g.nlines) return;
   const int64_t n = g.n, nl = g.nlines, pitch = g.outer;
   const int64_t nrows = nl - line0 < 64 ? nl - line0 : 64;  // live lines of this wave
-  const int64_t nb = (n + K - 1) / K;
   const int64_t nt = (n + W - 1) / W;
   // 16-B accesses need aligned rows; the per-lane byte offset must fit 32 bits
   const bool vec_ok = (pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0) &&
@@ -481,64 +557,78 @@ __global__ __launch_bounds__(256, 2) void iir_contig_kernel(const float *__restr
 
   float xb[K];
 
-  // ---------------- forward sweep: after block b (b <= nb-2) store checkpoint b+1 -------
+  // ---------------- forward sweep: a checkpoint in front of every tile >= 1 ----------------
   {
     CausalState s;
-    for (int64_t t = 0; t < nt && 2 * t + 1 < nb; ++t) {
+    for (int64_t t = 0; t + 1 < nt; ++t) {
       xtile_fill<W>(rows_in, tile, lane, nrows, pitch, t * W, n, vec_ok);
 #pragma clang loop unroll(disable)
       for (int h = 0; h < 2; ++h) {
-        const int64_t b = 2 * t + h;
-        if (b + 1 < nb) {
-          xtile_get<W, K>(tile, lane, h, xb);
-          if (b > 0) {
+        xtile_get<W, K>(tile, lane, h, xb);
+        if (t > 0 || h > 0) {
 #pragma unroll
-            for (int j = 0; j < K; ++j) causal_step(s, (double)xb[j], c);
-          } else {
-            const double x0 = (double)xb[0];
-            s.x1 = s.x2 = s.x3 = x0;
-            s.y1 = s.y2 = s.y3 = s.y4 = x0;
+          for (int j = 0; j < K; ++j) causal_step(s, (double)xb[j], c);
+        } else {
+          const double x0 = (double)xb[0];
+          s.x1 = s.x2 = s.x3 = x0;
+          s.y1 = s.y2 = s.y3 = s.y4 = x0;
 #pragma unroll
-            for (int j = 0; j < K; ++j) causal_step_edge(s, (double)xb[j], c, j);
-          }
-          if (live) ck_store(ck, b + 1, nl, line0, lane, s);
+          for (int j = 0; j < K; ++j) causal_step_edge(s, (double)xb[j], c, j);
         }
+      }
+      if (live) {
+        ck_store(ck, t + 1, nl, line0, lane, s);
+        ck_store_x(ck, t + 1, nl, line0, lane, s);
       }
       wave_lds_sync();  // reads of this tile are done before the next fill overwrites it
     }
   }
 
-  // ---------------- backward sweep ----------------
+  // ---------------- backward sweep, one tile (pair of blocks) per iteration ----------------
   {
     AntiState a;
     for (int64_t t = nt - 1; t >= 0; --t) {
-      xtile_fill<W>(rows_in, tile, lane, nrows, pitch, t * W, n, vec_ok);
+      const int64_t i0 = t * W, i1 = i0 + K;
+      xtile_fill<W>(rows_in, tile, lane, nrows, pitch, i0, n, vec_ok);
       if (t == nt - 1) {
         // x[n-1]: the clamped fill makes every slot past the line end hold it
         const double xN = (double)tile[lane * XTile<W>::PITCH + W - 1];
         a.x1 = a.x2 = a.x3 = a.x4 = xN;
         a.y1 = a.y2 = a.y3 = a.y4 = xN;
       }
-#pragma clang loop unroll(disable)
-      for (int h = 1; h >= 0; --h) {
-        const int64_t b = 2 * t + h;
-        if (b < nb) {
-          const int64_t i0 = b * K;
-          xtile_get<W, K>(tile, lane, h, xb);
-          CausalState s;
-          if (b > 0) {
-            ck_load(ck, b, nl, line0, live ? lane : 0u, s);
-          } else {
-            const double x0 = (double)xb[0];
-            s.x1 = s.x2 = s.x3 = x0;
-            s.y1 = s.y2 = s.y3 = s.y4 = x0;
-          }
-          const bool edge = (b == 0) || (i0 + K + 4 > n);
-          backward_block<K>(xb, s, a, c, i0, n, edge);
-          xtile_put<W, K>(tile, lane, h, xb);
-        }
+      CausalState s0;
+      float xa[K];
+      xtile_get<W, K>(tile, lane, 0, xa);
+      if (t > 0) {
+        ck_load(ck, t, nl, line0, live ? lane : 0u, s0);
+        ck_load_x(ck, t, nl, line0, live ? lane : 0u, s0);
+      } else {
+        const double x0 = (double)xa[0];
+        s0.x1 = s0.x2 = s0.x3 = x0;
+        s0.y1 = s0.y2 = s0.y3 = s0.y4 = x0;
       }
-      xtile_drain<W>(rows_out, tile, lane, nrows, pitch, t * W, n, vec_ok);
+      const bool head = t == 0;
+      double cz[K];
+      if (i1 < n) {
+        const bool tail = i1 + K + 4 > n;
+        CausalState s = s0;
+        causal_run<K, false>(s, xa, cz, c, i0, n, head);
+        xtile_get<W, K>(tile, lane, 1, xb);
+        causal_run<K, true>(s, xb, cz, c, i1, n, tail);
+        anti_run<K>(a, xb, cz, c, i1, n, tail);
+        xtile_put<W, K>(tile, lane, 1, xb);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const bool edge = head || (i0 + K + 4 > n);
+        CausalState s = s0;
+        opaque_state(s);
+        xtile_get<W, K>(tile, lane, 0, xa);
+        causal_run<K, true>(s, xa, cz, c, i0, n, edge);
+        anti_run<K>(a, xa, cz, c, i0, n, edge);
+        xtile_put<W, K>(tile, lane, 0, xa);
+      }
+      xtile_drain<W>(rows_out, tile, lane, nrows, pitch, i0, n, vec_ok);
     }
   }
 }
