@@ -30,10 +30,9 @@ PKG = "image-feature-extraction_amd"
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_VOXEL_SCALE = 37  # 4 (image) + 1 (mask) + 8*4 (out)
-# compulsory bytes per voxel of each kernel kind on its own (DESIGN.md "Kernels")
-KERNEL_ALG_BYTES = {"iir_z": 7.0,   # mean of numerator (4+1 in, 4 out) and denominator (1 in, 4 out)
-                    "iir_x": 8.0, "iir_y": 8.0, "features": 41.0}
-
+# compulsory bytes per voxel of ONE field pass / feature launch of each kernel kind
+# (DESIGN.md "Kernels"): a line-kernel launch covers several (scale, field) jobs
+KERNEL_ALG_BYTES = {"iir_z": 8.0, "iir_x": 8.0, "iir_y": 8.0, "features": 41.0, "prep": 13.0}
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -91,6 +90,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_slab
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = ""  # the RCCL version banner goes to stdout; keep it to the JSON line
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -142,16 +143,18 @@ def main():
     # ---- roofline: whole hot path, per step, from HIP events around every kernel ----
     kern = {}
     dev_ms_step = 0.0
+    nfields = 1 if args.mask == "none" else 2
     for name, (n, ms) in ktimes.items():
         per_step_ms = ms / args.steps
         dev_ms_step += per_step_ms
-        vox_per_launch = nvox / world
-        avg_ms = ms / n
-        e = {"launches_per_step": n / args.steps, "avg_ms": round(avg_ms, 4),
+        e = {"launches_per_step": n / args.steps, "avg_ms": round(ms / n, 4),
              "ms_per_step": round(per_step_ms, 4)}
         if name in KERNEL_ALG_BYTES:
-            gbs = KERNEL_ALG_BYTES[name] * vox_per_launch / (avg_ms * 1e-3) / 1e9
+            # units of work per step: field passes for the line kernels, scales for the rest
+            units = {"prep": 1, "features": len(sigmas)}.get(name, len(sigmas) * nfields)
+            gbs = KERNEL_ALG_BYTES[name] * units * (nvox / world) / (per_step_ms * 1e-3) / 1e9
             e["alg_bytes_per_voxel"] = KERNEL_ALG_BYTES[name]
+            e["units_per_step"] = units
             e["achieved_GBs"] = round(gbs, 1)
             e["frac"] = round(gbs / HBM_PEAK_GBS, 4)
         kern[name] = e

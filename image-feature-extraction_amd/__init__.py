@@ -38,7 +38,8 @@ EXPORTS = (
     "ife_normalized_gaussian_convolution", "ife_emphysema_features",
     "ife_fd_hessian_features", "ife_fd_gradient_features", "ife_mask_image_f64",
     "ife_get_kernel_times", "ife_reset_kernel_times",
-    "ife_stage_prepare", "ife_stage_recursive_gaussian", "ife_stage_features",
+    "ife_stage_prepare", "ife_stage_recursive_gaussian", "ife_stage_recursive_gaussian_batch",
+    "ife_stage_features",
 )
 
 
@@ -94,6 +95,8 @@ def load_library():
     lib.ife_mask_image_f64.argtypes = [vp, vp, vp, C.c_double, i64, vp, i32]
     lib.ife_stage_prepare.argtypes = [vp, vp, i32, vp, i32, i64, vp, vp]
     lib.ife_stage_recursive_gaussian.argtypes = [vp, vp, vp, vd, i32, C.c_double]
+    lib.ife_stage_recursive_gaussian_batch.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), vd,
+                                                       i32, C.POINTER(C.c_double)]
     lib.ife_stage_features.argtypes = [vp, vp, vp, vp, i32, vd, i32, i32, vp, i32]
     lib.ife_get_kernel_times.argtypes = [vp, C.POINTER(KernelTime), i32]
     lib.ife_reset_kernel_times.argtypes = [vp]
@@ -297,6 +300,17 @@ class Context:
         self._chk(self._lib.ife_stage_recursive_gaussian(
             self._h, C.c_void_p(in_ptr), C.c_void_p(out_ptr), C.byref(d), int(axis_xyz),
             float(sigma)))
+
+    def stage_recursive_gaussian_batch(self, in_ptrs, out_ptrs, shape_zyx, spacing, axis_xyz,
+                                       sigmas):
+        """One launch over len(in_ptrs) float volumes of the same shape (<= 8 jobs)."""
+        n = len(in_ptrs)
+        d = _desc(shape_zyx, spacing)
+        ins = (C.c_void_p * n)(*in_ptrs)
+        outs = (C.c_void_p * n)(*out_ptrs)
+        sg = (C.c_double * n)(*[float(s) for s in sigmas])
+        self._chk(self._lib.ife_stage_recursive_gaussian_batch(
+            self._h, n, ins, outs, C.byref(d), int(axis_xyz), sg))
 
     def stage_features(self, num_ptr, den_ptr, mask_ptr, mask_dtype, slab_shape_zyx, spacing,
                        halo_lo, halo_hi, out_ptr, layout=INTERLEAVED):

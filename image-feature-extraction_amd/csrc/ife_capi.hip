@@ -40,6 +40,7 @@ struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
 };
+constexpr int IFE_MAX_SLOTS = 3;
 
 struct ProfRec {
   int kind;
@@ -59,9 +60,11 @@ struct ife_ctx {
   int profile = 0;
   int zchunk = 64;
   int iir_block = 16;
-  DevBuf fld[4];  // num ping/pong, den ping/pong
+  // per scale slot: numerator ping/pong, denominator ping/pong (up to three scales run
+  // through the line kernels together)
+  DevBuf fld[IFE_MAX_SLOTS][4];
   DevBuf pre[2];  // image*certainty and certainty as float (prepass, shared by all scales)
-  DevBuf ck_y, ck_x;
+  DevBuf ck_y[IIR_MAX_JOBS], ck_x[IIR_MAX_JOBS];  // one checkpoint area per concurrent job
   DevBuf st_img, st_mask, st_aux, st_out;  // HOST-mode staging
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
@@ -245,7 +248,7 @@ IirGeom geom_for_axis(const ife_volume_desc *v, int axis) {
 
 size_t ck_pairs(int64_t n, int K) { return (size_t)((n + 2 * K - 1) / (2 * K)); }
 
-int ensure_ck(ife_ctx *ctx, const ife_volume_desc *v) {
+int ensure_ck(ife_ctx *ctx, const ife_volume_desc *v, int njobs) {
   const int K = ctx->iir_block;
   size_t need_y = 0, need_x = 0;
   for (int a = 0; a < 3; ++a) {
@@ -254,46 +257,61 @@ int ensure_ck(ife_ctx *ctx, const ife_volume_desc *v) {
     need_y = std::max(need_y, np * 4 * (size_t)g.nlines * sizeof(double));
     need_x = std::max(need_x, np * 3 * (size_t)g.nlines * sizeof(float));
   }
-  int rc = ensure(ctx, ctx->ck_y, need_y);
-  if (rc) return rc;
-  return ensure(ctx, ctx->ck_x, need_x);
+  for (int j = 0; j < njobs; ++j) {
+    int rc = ensure(ctx, ctx->ck_y[j], need_y);
+    if (!rc) rc = ensure(ctx, ctx->ck_x[j], need_x);
+    if (rc) return rc;
+  }
+  return IFE_OK;
 }
 
-template <typename SRC>
-int launch_strided(ife_ctx *ctx, SRC src, float *out, const ife_volume_desc *v, int axis,
-                   const IirCoef &c) {
-  IirGeom g = geom_for_axis(v, axis);
-  Checkpoint ck{(double *)ctx->ck_y.p, (float *)ctx->ck_x.p};
-  const unsigned blocks = (unsigned)((g.nlines + 255) / 256);
+int ensure_slots(ife_ctx *ctx, const ife_volume_desc *v, int nslots) {
+  const size_t nb = (size_t)(v->nx * v->ny * v->nz) * sizeof(float);
+  for (int s = 0; s < nslots; ++s)
+    for (int i = 0; i < 4; ++i) {
+      int rc = ensure(ctx, ctx->fld[s][i], nb);
+      if (rc) return rc;
+    }
+  return IFE_OK;
+}
+
+// One launch of the line kernel along `axis` over njobs independent float volumes
+// (jobs = numerator / denominator of up to three scales), each with its own sigma.
+int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
+               const float *const *in, float *const *out, const double *sigma) {
+  if (njobs < 1 || njobs > IIR_MAX_JOBS) return fail(ctx, IFE_E_ARG, "bad job count %d", njobs);
+  const IirGeom g = geom_for_axis(v, axis);
   // 32-bit offsets of the buffer accesses (iir_kernels.hpp "addressing")
   if ((int64_t)2 * ctx->iir_block * g.sstride * 4 >= (int64_t)1 << 31 ||
       g.outer * 4 >= (int64_t)1 << 32 || g.nlines * 8 * 3 >= (int64_t)1 << 32)
     return fail(ctx, IFE_E_SIZE, "volume too large for the 32-bit offsets of the line kernels");
-  ProfScope ps(ctx, axis == 2 ? KK_IIR_Z : KK_IIR_Y);
-  if (ctx->iir_block == 8)
-    hipLaunchKernelGGL((iir_strided_kernel<8, SRC>), dim3(blocks), dim3(256), 0, ctx->stream, src,
-                       out, g, c, ck);
-  else
-    hipLaunchKernelGGL((iir_strided_kernel<16, SRC>), dim3(blocks), dim3(256), 0, ctx->stream,
-                       src, out, g, c, ck);
-  IFE_HIP(ctx, hipGetLastError());
-  return IFE_OK;
-}
-
-int launch_contig(ife_ctx *ctx, const float *in, float *out, const ife_volume_desc *v,
-                  const IirCoef &c) {
-  IirGeom g = geom_for_axis(v, 0);
-  Checkpoint ck{(double *)ctx->ck_y.p, (float *)ctx->ck_x.p};
-  const unsigned blocks = (unsigned)((g.nlines + 255) / 256);
-  if (g.nlines * 8 * 3 >= (int64_t)1 << 32)
-    return fail(ctx, IFE_E_SIZE, "volume too large for the 32-bit offsets of the line kernels");
-  ProfScope ps(ctx, KK_IIR_X);
-  if (ctx->iir_block == 8)
-    hipLaunchKernelGGL((iir_contig_kernel<8>), dim3(blocks), dim3(256), 0, ctx->stream, in, out,
-                       g, c, ck);
-  else
-    hipLaunchKernelGGL((iir_contig_kernel<16>), dim3(blocks), dim3(256), 0, ctx->stream, in, out,
-                       g, c, ck);
+  int rc = ensure_ck(ctx, v, njobs);
+  if (rc) return rc;
+  const double sp = axis == 0 ? v->sx : axis == 1 ? v->sy : v->sz;
+  IirJobs jobs;
+  memset(&jobs, 0, sizeof jobs);
+  for (int j = 0; j < njobs; ++j) {
+    if (!in[j] || !out[j] || in[j] == out[j]) return fail(ctx, IFE_E_ARG, "bad job buffers");
+    jobs.j[j].in = in[j];
+    jobs.j[j].out = out[j];
+    jobs.j[j].ck_y = (double *)ctx->ck_y[j].p;
+    jobs.j[j].ck_x = (float *)ctx->ck_x[j].p;
+    if (gauss_coeffs(sigma[j], sp, &jobs.j[j].c))
+      return fail(ctx, IFE_E_ARG, "spacing is suspiciously small");
+  }
+  const dim3 grid((unsigned)((g.nlines + 255) / 256), (unsigned)njobs, 1);
+  ProfScope ps(ctx, axis == 2 ? KK_IIR_Z : axis == 1 ? KK_IIR_Y : KK_IIR_X);
+  if (axis == 0) {
+    if (ctx->iir_block == 8)
+      hipLaunchKernelGGL((iir_contig_kernel<8>), grid, dim3(256), 0, ctx->stream, jobs, g);
+    else
+      hipLaunchKernelGGL((iir_contig_kernel<16>), grid, dim3(256), 0, ctx->stream, jobs, g);
+  } else {
+    if (ctx->iir_block == 8)
+      hipLaunchKernelGGL((iir_strided_kernel<8>), grid, dim3(256), 0, ctx->stream, jobs, g);
+    else
+      hipLaunchKernelGGL((iir_strided_kernel<16>), grid, dim3(256), 0, ctx->stream, jobs, g);
+  }
   IFE_HIP(ctx, hipGetLastError());
   return IFE_OK;
 }
@@ -321,18 +339,36 @@ int launch_prep(ife_ctx *ctx, const TI *img, const TM *msk, float *tc, float *cf
   return IFE_OK;
 }
 
-// SmoothingRecursiveGaussianImageFilter: Z pass from `src`, then X, then Y.
-// Result lands in buf_a (buf_b is the intermediate).
-template <typename SRC>
-int smooth_field(ife_ctx *ctx, SRC src, float *buf_a, float *buf_b, const ife_volume_desc *v,
-                 double sigma) {
-  IirCoef cz, cx, cy;
-  if (gauss_coeffs(sigma, v->sz, &cz) || gauss_coeffs(sigma, v->sx, &cx) ||
-      gauss_coeffs(sigma, v->sy, &cy))
-    return fail(ctx, IFE_E_ARG, "spacing is suspiciously small");
-  int rc = launch_strided(ctx, src, buf_a, v, 2, cz);
-  if (!rc) rc = launch_contig(ctx, buf_a, buf_b, v, cx);
-  if (!rc) rc = launch_strided(ctx, SrcF32{buf_b}, buf_a, v, 1, cy);
+// SmoothingRecursiveGaussianImageFilter for a group of up to IFE_MAX_SLOTS scales at
+// once: Z pass from the shared sources (image*certainty, certainty), then X, then Y, each
+// axis as ONE launch over all (scale, field) jobs.  Scale k of the group ends in slot k:
+// numerator in fld[k][0], denominator in fld[k][2].
+int smooth_group(ife_ctx *ctx, const float *src_num, const float *src_den,
+                 const ife_volume_desc *v, const double *sigmas, int nscales) {
+  const int nf = src_den ? 2 : 1;
+  const float *in[IIR_MAX_JOBS];
+  float *out[IIR_MAX_JOBS];
+  double sg[IIR_MAX_JOBS];
+  int nj = 0;
+  for (int k = 0; k < nscales; ++k)
+    for (int f = 0; f < nf; ++f) sg[nj++] = sigmas[k];
+  int rc = ensure_slots(ctx, v, nscales);
+  if (rc) return rc;
+  auto fill = [&](int src_idx, int dst_idx, bool from_source) {
+    int j = 0;
+    for (int k = 0; k < nscales; ++k)
+      for (int f = 0; f < nf; ++f, ++j) {
+        in[j] = from_source ? (f == 0 ? src_num : src_den)
+                            : (const float *)ctx->fld[k][2 * f + src_idx].p;
+        out[j] = (float *)ctx->fld[k][2 * f + dst_idx].p;
+      }
+  };
+  fill(0, 0, true);                                    // Z: sources -> ping
+  rc = launch_iir(ctx, v, 2, nj, in, out, sg);
+  fill(0, 1, false);                                   // X: ping -> pong
+  if (!rc) rc = launch_iir(ctx, v, 0, nj, in, out, sg);
+  fill(1, 0, false);                                   // Y: pong -> ping
+  if (!rc) rc = launch_iir(ctx, v, 1, nj, in, out, sg);
   return rc;
 }
 
@@ -429,8 +465,6 @@ template <typename TI, typename TM>
 static int emphysema_typed(ife_ctx *ctx, const TI *img, const TM *msk, const ife_volume_desc *vol,
                            const float *sigmas, int n_sigmas, float *dout, int layout) {
   const size_t n = (size_t)(vol->nx * vol->ny * vol->nz);
-  float *num = (float *)ctx->fld[0].p, *numb = (float *)ctx->fld[1].p;
-  float *den = (float *)ctx->fld[2].p, *denb = (float *)ctx->fld[3].p;
   float *tc = (float *)ctx->pre[0].p, *cf = (float *)ctx->pre[1].p;
   // Cast + Multiply once for all scales (the reference redoes them per scale, a9).
   // mask == NULL: certainty == 1 everywhere, image*1 is the image and G(1) is exactly
@@ -443,13 +477,16 @@ static int emphysema_typed(ife_ctx *ctx, const TI *img, const TM *msk, const ife
     if (rc) return rc;
     src_num = tc;
   }
-  for (int s = 0; s < n_sigmas; ++s) {
-    const double sigma = (double)sigmas[s];
-    int rc = smooth_field(ctx, SrcF32{src_num}, num, numb, vol, sigma);
-    if (!rc && msk) rc = smooth_field(ctx, SrcF32{cf}, den, denb, vol, sigma);
-    if (rc) return rc;
-    rc = launch_features<FEAT_FEATURES8>(ctx, ValSmooth{num, msk ? den : nullptr}, msk,
-                                         dout + (size_t)s * n * IFE_NUM_FEATURES, vol, layout);
+  for (int s0 = 0; s0 < n_sigmas; s0 += IFE_MAX_SLOTS) {
+    const int ns = std::min(IFE_MAX_SLOTS, n_sigmas - s0);
+    double sg[IFE_MAX_SLOTS];
+    for (int k = 0; k < ns; ++k) sg[k] = (double)sigmas[s0 + k];
+    int rc = smooth_group(ctx, src_num, msk ? cf : nullptr, vol, sg, ns);
+    for (int k = 0; k < ns && !rc; ++k)
+      rc = launch_features<FEAT_FEATURES8>(
+          ctx, ValSmooth{(const float *)ctx->fld[k][0].p,
+                         msk ? (const float *)ctx->fld[k][2].p : nullptr},
+          msk, dout + (size_t)(s0 + k) * n * IFE_NUM_FEATURES, vol, layout);
     if (rc) return rc;
   }
   return IFE_OK;
@@ -487,9 +524,12 @@ void ife_ctx_destroy(ife_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  DevBuf *bufs[] = {&ctx->fld[0], &ctx->fld[1], &ctx->fld[2], &ctx->fld[3], &ctx->pre[0],
-                    &ctx->pre[1], &ctx->ck_y,
-                    &ctx->ck_x,   &ctx->st_img, &ctx->st_mask, &ctx->st_aux, &ctx->st_out};
+  std::vector<DevBuf *> bufs = {&ctx->pre[0], &ctx->pre[1], &ctx->st_img, &ctx->st_mask,
+                                &ctx->st_aux, &ctx->st_out};
+  for (auto &sl : ctx->fld)
+    for (auto &b : sl) bufs.push_back(&b);
+  for (auto &b : ctx->ck_y) bufs.push_back(&b);
+  for (auto &b : ctx->ck_x) bufs.push_back(&b);
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -539,9 +579,9 @@ int ife_ctx_reserve(ife_ctx *ctx, const ife_volume_desc *vol) {
   rc = check_vol(ctx, vol, false);
   if (rc) return rc;
   const size_t nb = (size_t)(vol->nx * vol->ny * vol->nz) * sizeof(float);
-  for (int i = 0; i < 4 && !rc; ++i) rc = ensure(ctx, ctx->fld[i], nb);
+  rc = ensure_slots(ctx, vol, IFE_MAX_SLOTS);
   for (int i = 0; i < 2 && !rc; ++i) rc = ensure(ctx, ctx->pre[i], nb);
-  if (!rc) rc = ensure_ck(ctx, vol);
+  if (!rc) rc = ensure_ck(ctx, vol, 2 * IFE_MAX_SLOTS);
   return rc;
 }
 
@@ -626,14 +666,13 @@ int ife_normalized_gaussian_convolution(ife_ctx *ctx, const float *image,
   if ((rc = stage_in(ctx, mem, image, n * 4, ctx->st_img, &dI))) return rc;
   if ((rc = stage_in(ctx, mem, certainty, n * 4, ctx->st_aux, &dC))) return rc;
   if ((rc = stage_out_begin(ctx, mem, out, n * 4, &dO))) return rc;
-  float *num = (float *)ctx->fld[0].p, *numb = (float *)ctx->fld[1].p;
-  float *den = (float *)ctx->fld[2].p, *denb = (float *)ctx->fld[3].p;
   float *tc = (float *)ctx->pre[0].p;
   rc = launch_prep<float, float>(ctx, (const float *)dI, (const float *)dC, tc, nullptr,
                                  (int64_t)n);
-  if (!rc) rc = smooth_field(ctx, SrcF32{tc}, num, numb, vol, sigma);
-  if (!rc) rc = smooth_field(ctx, SrcF32{(const float *)dC}, den, denb, vol, sigma);
+  const double sg = sigma;
+  if (!rc) rc = smooth_group(ctx, tc, (const float *)dC, vol, &sg, 1);
   if (rc) return rc;
+  const float *num = (const float *)ctx->fld[0][0].p, *den = (const float *)ctx->fld[0][2].p;
   {
     ProfScope ps(ctx, KK_DIVIDE);
     hipLaunchKernelGGL(divide_kernel, dim3(2048), dim3(256), 0, ctx->stream, num, den,
@@ -795,12 +834,26 @@ int ife_stage_recursive_gaussian(ife_ctx *ctx, const float *in, float *out,
   if (len < 4)
     return fail(ctx, IFE_E_SIZE, "the recursive Gaussian needs at least 4 voxels along axis %d",
                 axis);
-  if ((rc = ensure_ck(ctx, vol))) return rc;
-  IirCoef c;
-  const double sp = axis == 0 ? vol->sx : axis == 1 ? vol->sy : vol->sz;
-  if (gauss_coeffs(sigma, sp, &c)) return fail(ctx, IFE_E_ARG, "spacing is suspiciously small");
-  if (axis == 0) return launch_contig(ctx, in, out, vol, c);
-  return launch_strided(ctx, SrcF32{in}, out, vol, axis, c);
+  const float *ins[1] = {in};
+  float *outs[1] = {out};
+  return launch_iir(ctx, vol, axis, 1, ins, outs, &sigma);
+}
+
+int ife_stage_recursive_gaussian_batch(ife_ctx *ctx, int njobs, const float *const *in,
+                                       float *const *out, const ife_volume_desc *vol, int axis,
+                                       const double *sigmas) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_vol(ctx, vol, false))) return rc;
+  if (!in || !out || !sigmas) return fail(ctx, IFE_E_ARG, "null pointer");
+  if (axis < 0 || axis > 2) return fail(ctx, IFE_E_ARG, "axis must be 0 (x), 1 (y) or 2 (z)");
+  for (int j = 0; j < njobs; ++j)
+    if (!(sigmas[j] > 0.0)) return fail(ctx, IFE_E_ARG, "sigma must be positive");
+  const int64_t len = axis == 0 ? vol->nx : axis == 1 ? vol->ny : vol->nz;
+  if (len < 4)
+    return fail(ctx, IFE_E_SIZE, "the recursive Gaussian needs at least 4 voxels along axis %d",
+                axis);
+  return launch_iir(ctx, vol, axis, njobs, in, out, sigmas);
 }
 
 int ife_stage_features(ife_ctx *ctx, const float *num, const float *den, const void *mask,

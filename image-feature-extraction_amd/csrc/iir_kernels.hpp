@@ -155,41 +155,34 @@ __device__ __forceinline__ float buf_ld_as_f32<int16_t>(rsrc_t r, uint32_t voff,
   return (float)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
 }
 
-// ---- sample sources ------------------------------------------------------------
-// at(u): resources based at uniform element index u;  ld(B, v, s): element at per-lane
-// element offset v plus scalar element offset s from that base.
-// SrcF32: a float volume (X and Y passes, certainty given as float)
-// SrcMul<TI,TM>: image*certainty with certainty = float(mask)
-//   (MultiplyImageFilter, NormalizedGaussianConvolutionImageFilter.hxx:48-49, after
-//    CastImageFilter, ImageToEmphysemaFeaturesFilter.hxx:21,110)
-// SrcImg<T>: float(volume of T) (the certainty itself, or the image when it is all ones)
-template <typename TI>
-struct SrcImg {
-  const TI *img;
+// ---- jobs ------------------------------------------------------------------------
+// One launch runs up to IIR_MAX_JOBS independent line filters of the same geometry
+// (numerator and denominator of up to three scales): blockIdx.y selects the job.  All
+// line kernels read and write float volumes (the cast/multiply prepass feeds the first).
+constexpr int IIR_MAX_JOBS = 8;
+struct IirJob {
+  const float *in;
+  float *out;
+  double *ck_y;  // [npairs][4][nlines]: y[i-1..i-4] at the start of every second block
+  float *ck_x;   // [npairs][3][nlines]: x[i-1..i-3], contiguous-axis kernel only
+  IirCoef c;
+};
+struct IirJobs {
+  IirJob j[IIR_MAX_JOBS];
+};
+
+struct SrcF32 {
+  const float *p;
   struct At { rsrc_t a; };
-  __device__ __forceinline__ At at(int64_t u) const { return At{make_rsrc(img + u)}; }
+  __device__ __forceinline__ At at(int64_t u) const { return At{make_rsrc(p + u)}; }
   __device__ __forceinline__ float ld(const At &b, uint32_t v, uint32_t s) const {
-    return buf_ld_as_f32<TI>(b.a, v * (uint32_t)sizeof(TI), s * (uint32_t)sizeof(TI));
+    return buf_ld_f32(b.a, v * 4u, s * 4u);
   }
 };
-using SrcF32 = SrcImg<float>;
-template <typename TI, typename TM>
-struct SrcMul {
-  const TI *img;
-  const TM *msk;
-  struct At { rsrc_t a, m; };
-  __device__ __forceinline__ At at(int64_t u) const {
-    return At{make_rsrc(img + u), make_rsrc(msk + u)};
-  }
-  __device__ __forceinline__ float ld(const At &b, uint32_t v, uint32_t s) const {
-    return buf_ld_as_f32<TI>(b.a, v * (uint32_t)sizeof(TI), s * (uint32_t)sizeof(TI)) *
-           buf_ld_as_f32<TM>(b.m, v * (uint32_t)sizeof(TM), s * (uint32_t)sizeof(TM));
-  }
-};
-using SrcMulF = SrcMul<float, float>;
+
 struct Checkpoint {
-  double *y;  // [npairs][4][nlines]: y[i-1..i-4] at the start of every second block
-  float *x;   // [npairs][3][nlines]: x[i-1..i-3], contiguous-axis kernel only
+  double *y;
+  float *x;
 };
 
 // The recursion state is saved once per PAIR of register blocks (every 2K samples); the
@@ -286,9 +279,13 @@ __device__ __forceinline__ void anti_run(AntiState &a, float (&x)[K], const doub
 // =================================================================================
 // strided axes (Z and Y)
 // =================================================================================
-template <int K, typename SRC>
-__global__ __launch_bounds__(256) void iir_strided_kernel(SRC src, float *__restrict__ out,
-                                                          IirGeom g, IirCoef c, Checkpoint ck) {
+template <int K>
+__global__ __launch_bounds__(256) void iir_strided_kernel(IirJobs jobs, IirGeom g) {
+  const IirJob &J = jobs.j[blockIdx.y];
+  const SrcF32 src{J.in};
+  float *__restrict__ out = J.out;
+  const IirCoef c = J.c;
+  const Checkpoint ck{J.ck_y, J.ck_x};
   const uint32_t lane = threadIdx.x & 63u;
   const int64_t Lw =
       uniform64((int64_t)blockIdx.x * blockDim.x + (int64_t)(threadIdx.x & ~63u));
@@ -534,9 +531,12 @@ __device__ __forceinline__ void xtile_drain(float *rows, float *tile, uint32_t l
 }
 
 template <int K>
-__global__ __launch_bounds__(256, 2) void iir_contig_kernel(const float *__restrict__ in,
-                                                         float *__restrict__ out, IirGeom g,
-                                                         IirCoef c, Checkpoint ck) {
+__global__ __launch_bounds__(256, 2) void iir_contig_kernel(IirJobs jobs, IirGeom g) {
+  const IirJob &J = jobs.j[blockIdx.y];
+  const float *__restrict__ in = J.in;
+  float *__restrict__ out = J.out;
+  const IirCoef c = J.c;
+  const Checkpoint ck{J.ck_y, J.ck_x};
   constexpr int W = 2 * K;  // tile width: two register blocks
   __shared__ __attribute__((aligned(16))) float lds[4 * XTile<W>::FLOATS];
   const uint32_t lane = threadIdx.x & 63u;

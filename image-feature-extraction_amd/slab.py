@@ -21,8 +21,9 @@ is the one stage a Z-slab cut cannot keep local.  Re-cutting the two smoothing i
 along Y for that pass keeps the arithmetic exactly the sequential recursion of the
 single-GPU path (results are bit-identical to it), at the price of moving 8 B/voxel/scale
 across xGMI; each rank talks to all W-1 peers at once, so all seven links carry
-traffic.  The all-to-all of scale s+1 is issued before the X/Y/feature kernels of scale s,
-which hides it behind compute.
+traffic.  The Z passes of all scales run first (batched into
+few launches, because a slab has few lines per field), then every scale's all-to-all is
+issued at once, so the exchanges of scales s+1.. travel while scale s computes.
 
 Nothing here touches the oracle: `stages` is the C-ABI (HipStages).  Tests substitute
 their own stage object to exercise this orchestration on CPU with gloo.
@@ -44,9 +45,11 @@ class HipStages:
                                mdt, img.numel(), tc.data_ptr(),
                                cf.data_ptr() if cf is not None else None)
 
-    def gaussian_axis(self, src, dst, spacing, axis, sigma):
-        self.ctx.stage_recursive_gaussian(src.data_ptr(), dst.data_ptr(), tuple(src.shape),
-                                          spacing, axis, sigma)
+    def gaussian_axis_batch(self, srcs, dsts, spacing, axis, sigmas):
+        """One launch over several float volumes of the same shape (jobs)."""
+        self.ctx.stage_recursive_gaussian_batch([t.data_ptr() for t in srcs],
+                                                [t.data_ptr() for t in dsts],
+                                                tuple(srcs[0].shape), spacing, axis, sigmas)
 
     def features(self, num, den, mask, slab_shape, spacing, halo_lo, halo_hi, out, layout):
         mdt = self.pkg.U8 if mask is None or mask.element_size() == 1 else self.pkg.U16
@@ -123,14 +126,16 @@ class SlabEngine:
         nzl, nyl, W = self.nzl, self.nyl, world
         f = lambda *shp: empty(shp)  # float32 buffers
         nf = 2 if has_mask else 1
+        S = len(self.sigmas)
+        self.group = 4 if nf == 2 else 8              # scales per line-kernel launch (<= 8 jobs)
         self.src_z = [f(nzl, ny, nx) for _ in range(nf)]          # tc, cf (Z-slab)
         self.pack = f(W, nzl, nyl, nx)                            # all-to-all staging
         self.src_y = [f(W, nzl, nyl, nx) for _ in range(nf)]      # tc, cf (Y-slab == [nz][nyl][nx])
-        # per scale parity: Z-pass output (Y-slab) and its Z-slab image after exchange #1
-        self.zy = [[f(W, nzl, nyl, nx) for _ in range(nf)] for _ in range(2)]
-        self.zz = [[f(W, nzl, nyl, nx) for _ in range(nf)] for _ in range(2)]
-        self.a = f(nzl, ny, nx)                                   # permuted / X-pass ping-pong
-        self.b = f(nzl, ny, nx)
+        # per scale: Z-pass output (Y-slab) and its Z-slab image after exchange #1
+        self.zy = [[f(W, nzl, nyl, nx) for _ in range(nf)] for _ in range(S)]
+        self.zz = [[f(W, nzl, nyl, nx) for _ in range(nf)] for _ in range(S)]
+        self.a = [f(nzl, ny, nx) for _ in range(nf)]              # unpacked Z-pass output
+        self.b = [f(nzl, ny, nx) for _ in range(nf)]              # X-pass output
         self.pad = [f(nzl + 2, ny, nx) for _ in range(nf)]        # Y-pass output + halo planes
 
     # Z-slab [nzl][ny][nx] -> chunks by destination rank [W][nzl][nyl][nx]
@@ -148,42 +153,40 @@ class SlabEngine:
         nf = 2 if self.has_mask else 1
         yshape = (self.nz, self.nyl, self.nx)
         sp = self.spacing
+        S = len(self.sigmas)
         st.prepare(img_slab, mask_slab if self.has_mask else None, self.src_z[0],
                    self.src_z[1] if self.has_mask else None)
         for k in range(nf):                                   # exchange #0
             self._pack_z(self.src_z[k], self.pack)
             comm.all_to_all(self.pack, self.src_y[k])
-        pending = {}
-        S = len(self.sigmas)
-        for s in range(S + 1):
-            if s < S:                                         # Z pass of scale s + exchange #1
-                par = s & 1
-                works = []
-                for k in range(nf):
-                    st.gaussian_axis(self.src_y[k].view(yshape), self.zy[par][k].view(yshape), sp, 2,
-                                     self.sigmas[s])
-                    works.append(comm.all_to_all(self.zy[par][k], self.zz[par][k],
-                                                 async_op=self.overlap))
-                pending[s] = works
-            if s >= 1:                                        # X, Y, halo, features of scale s-1
-                t = s - 1
-                par = t & 1
-                for w in pending.pop(t):
-                    if w is not None:
-                        w.wait()
-                for k in range(nf):
-                    self._unpack_z(self.zz[par][k], self.a)
-                    st.gaussian_axis(self.a, self.b, sp, 0, self.sigmas[t])
-                    st.gaussian_axis(self.b, self.pad[k][1:self.nzl + 1], sp, 1, self.sigmas[t])
-                for k in range(nf):                           # exchange #2
-                    p = self.pad[k]
-                    comm.halo(p[1], p[self.nzl], p[0], p[self.nzl + 1])
-                lo = 1 if self.rank > 0 else 0
-                hi = 1 if self.rank < self.W - 1 else 0
-                first = 0 if lo else 1
-                st.features(self.pad[0][first:], self.pad[1][first:] if self.has_mask else None,
-                            mask_slab if self.has_mask else None, (self.nzl, self.ny, self.nx), sp,
-                            lo, hi, out[t], self.layout)
+        # Z pass of every scale and field in as few launches as possible (a slab has few
+        # lines; one job per launch would leave most of the device idle), then all the
+        # exchanges #1 back to back: those of scale s+1.. travel while scale s computes.
+        for s0 in range(0, S, self.group):
+            ss = range(s0, min(S, s0 + self.group))
+            st.gaussian_axis_batch([self.src_y[k].view(yshape) for s in ss for k in range(nf)],
+                                   [self.zy[s][k].view(yshape) for s in ss for k in range(nf)],
+                                   sp, 2, [self.sigmas[s] for s in ss for k in range(nf)])
+        pending = [[comm.all_to_all(self.zy[s][k], self.zz[s][k], async_op=self.overlap)
+                    for k in range(nf)] for s in range(S)]
+        lo = 1 if self.rank > 0 else 0
+        hi = 1 if self.rank < self.W - 1 else 0
+        first = 0 if lo else 1
+        for s in range(S):                                    # X, Y, halo, features of scale s
+            for w in pending[s]:
+                if w is not None:
+                    w.wait()
+            for k in range(nf):
+                self._unpack_z(self.zz[s][k], self.a[k])
+            sg = [self.sigmas[s]] * nf
+            st.gaussian_axis_batch(self.a[:nf], self.b[:nf], sp, 0, sg)
+            st.gaussian_axis_batch(self.b[:nf], [p[1:self.nzl + 1] for p in self.pad[:nf]], sp, 1, sg)
+            for k in range(nf):                               # exchange #2
+                p = self.pad[k]
+                comm.halo(p[1], p[self.nzl], p[0], p[self.nzl + 1])
+            st.features(self.pad[0][first:], self.pad[1][first:] if self.has_mask else None,
+                        mask_slab if self.has_mask else None, (self.nzl, self.ny, self.nx), sp,
+                        lo, hi, out[s], self.layout)
 
 
 class SlabRunner:

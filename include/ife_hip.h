@@ -192,6 +192,12 @@ int ife_stage_prepare(ife_ctx *ctx, const void *image, int image_dtype, const vo
  * caller keeps ITK's order z, x, y.  Not in place. */
 int ife_stage_recursive_gaussian(ife_ctx *ctx, const float *in, float *out,
                                  const ife_volume_desc *vol, int axis, double sigma);
+/* The same over njobs (<= 8) float volumes of one geometry in a single launch, each with
+ * its own sigma: numerator and denominator of several scales.  A slab host needs this to
+ * keep the device full (a 64-plane slab has too few lines for one job per launch). */
+int ife_stage_recursive_gaussian_batch(ife_ctx *ctx, int njobs, const float *const *in,
+                                       float *const *out, const ife_volume_desc *vol, int axis,
+                                       const double *sigmas);
 /* Everything after the smoothing (ImageToEmphysemaFeaturesFilter.hxx:27-54 plus the
  * Divide of NormalizedGaussianConvolutionImageFilter.hxx:57-61) on a slab of slab->nz
  * planes.  num/den hold halo_lo + slab->nz + halo_hi planes: with halo_lo (halo_hi) = 1

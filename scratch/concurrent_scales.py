@@ -1,0 +1,28 @@
+import importlib, sys, time, numpy as np, torch
+sys.path.insert(0,'.')
+ife=importlib.import_module("image-feature-extraction_amd")
+synth=importlib.import_module("image-feature-extraction_amd.synthetic")
+n=512; shape=(n,n,n)
+img=torch.from_numpy(synth.volume_f32(shape,synth.SEED_CONFIG[3])).cuda()
+mask=torch.ones(shape,dtype=torch.uint8,device='cuda')
+sigmas=[1.0,2.0,4.0]
+out=torch.empty((3,n,n,n,8),dtype=torch.float32,device='cuda')
+def bench(nstreams, reps=5):
+    streams=[torch.cuda.Stream() for _ in range(nstreams)]
+    ctxs=[]
+    for s in streams:
+        c=ife.Context(0); c.set_stream(s.cuda_stream); c.reserve(shape); ctxs.append(c)
+    def step():
+        cur=torch.cuda.current_stream()
+        for k,sig in enumerate(sigmas):
+            st=streams[k%nstreams]; st.wait_stream(cur)
+            ctxs[k%nstreams].emphysema_features_device(img.data_ptr(), ife.F32, mask.data_ptr(), ife.U8, shape,(1.,1.,1.), [sig], out[k].data_ptr())
+        for st in streams: cur.wait_stream(st)
+    step(); torch.cuda.synchronize()
+    t0=time.perf_counter()
+    for _ in range(reps): step()
+    torch.cuda.synchronize()
+    dt=(time.perf_counter()-t0)/reps*1e3
+    print('streams',nstreams,'ms/step %.3f'%dt)
+    for c in ctxs: c.close()
+for ns in (1,2,3): bench(ns)

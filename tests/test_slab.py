@@ -40,10 +40,11 @@ class OracleStages:
             tc.copy_(img.float() * mask.float())
             cf.copy_(mask.float())
 
-    def gaussian_axis(self, src, dst, spacing, axis, sigma):
+    def gaussian_axis_batch(self, srcs, dsts, spacing, axis, sigmas):
         import torch
-        dst.copy_(torch.from_numpy(
-            self.o.recursive_gaussian_axis(src.contiguous().numpy(), axis, sigma, spacing)))
+        for src, dst, sigma in zip(srcs, dsts, sigmas):
+            dst.copy_(torch.from_numpy(
+                self.o.recursive_gaussian_axis(src.contiguous().numpy(), axis, sigma, spacing)))
 
     def features(self, num, den, mask, slab_shape, spacing, halo_lo, halo_hi, out, layout):
         import torch
