@@ -103,7 +103,9 @@ __device__ __forceinline__ float div_by_const(float x) {
   const float q = x * y;
   float f = fmaf(fmaf(-d, q, x), y, q);
   f = ax == 0.0f ? x : f;
-  if (!(ax <= 0x1p100f) || (ax < 0x1p-100f && ax != 0.0f)) f = x / d;
+  // rare: one wave-uniform branch instead of a per-lane exec region on the common path
+  const bool odd = !(ax <= 0x1p100f) || (ax < 0x1p-100f && ax != 0.0f);
+  if (__builtin_amdgcn_ballot_w64(odd) != 0) f = odd ? x / d : f;
   return f;
 }
 __device__ __forceinline__ float div_by_3(float x) { return div_by_const<3>(x); }
@@ -200,8 +202,7 @@ __device__ __forceinline__ Eig3 eig3_sym_fast(float A11, float A12, float A13, f
   p = d1 * d1 + d2 * d2 + d3 * d3 + 2.0f * p;
   p = sqrtf(div_by_6(p));
   const float ap = fabsf(p);
-  const bool safe = ap >= 0x1p-60f && ap <= 0x1p60f;
-  if (!diag && !safe) return eig3_sym_generic_call(A11, A12, A13, A22, A23, A33);
+  const bool unsafe = !diag && !(ap >= 0x1p-60f && ap <= 0x1p60f);
   const SharedRecip rp = shared_recip(p);
   const float B11 = div_shared(d1, rp), B12 = div_shared(A12, rp), B13 = div_shared(A13, rp);
   const float B22 = div_shared(d2, rp), B23 = div_shared(A23, rp), B33 = div_shared(d3, rp);
@@ -223,18 +224,23 @@ __device__ __forceinline__ Eig3 eig3_sym_fast(float A11, float A12, float A13, f
   if (fabsf(e1) < fabsf(e2)) { const float t = e1; e1 = e2; e2 = t; }
   Eig3 r;
   r.e0 = e0; r.e1 = e1; r.e2 = e2;
-  if (diag) {
+  // Both special cases are rare and are entered per WAVE (scalar branch on a ballot), so
+  // the common path carries no per-lane exec regions; inside, lanes select.
+  if (__builtin_amdgcn_ballot_w64(diag) != 0) {
     const float a1 = fabsf(A11), a2 = fabsf(A22), a3 = fabsf(A33);
     const bool c12 = a1 > a2, c13 = a1 > a3, c23 = a2 > a3;
-    if (c12) {
-      r.e0 = c13 ? A11 : A33;
-      r.e1 = c13 ? (c23 ? A22 : A33) : A11;
-      r.e2 = c13 ? (c23 ? A33 : A22) : A22;
-    } else {
-      r.e0 = c23 ? A22 : A33;
-      r.e1 = c23 ? (c13 ? A11 : A33) : A22;
-      r.e2 = c23 ? (c13 ? A33 : A11) : A11;
-    }
+    const float d0 = c12 ? (c13 ? A11 : A33) : (c23 ? A22 : A33);
+    const float d1 = c12 ? (c13 ? (c23 ? A22 : A33) : A11) : (c23 ? (c13 ? A11 : A33) : A22);
+    const float d2 = c12 ? (c13 ? (c23 ? A33 : A22) : A22) : (c23 ? (c13 ? A33 : A11) : A11);
+    r.e0 = diag ? d0 : r.e0;
+    r.e1 = diag ? d1 : r.e1;
+    r.e2 = diag ? d2 : r.e2;
+  }
+  if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {
+    const Eig3 g = eig3_sym_generic_call(A11, A12, A13, A22, A23, A33);
+    r.e0 = unsafe ? g.e0 : r.e0;
+    r.e1 = unsafe ? g.e1 : r.e1;
+    r.e2 = unsafe ? g.e2 : r.e2;
   }
   return r;
 }

@@ -62,20 +62,30 @@ struct DerivCoef {
 // value sources -------------------------------------------------------------------
 // Smoothed field S = num/den with ITK's Div functor (B != 0 ? A/B : max()); den may
 // be null when the certainty is identically one (then den == 1.0f exactly).
+// A source is read in two steps so that the loads of plane z+2 stay in flight across the
+// arithmetic of plane z: fetch() only issues loads, finish() (called one plane later, just
+// before the LDS write) turns the raw registers into the float value.
 struct ValSmooth {
   const float *num;
   const float *den;
-  __device__ __forceinline__ float ld(int64_t i) const {
-    const float a = num[i];
-    if (den == nullptr) return a;
-    const float b = den[i];
-    return b != 0.0f ? a / b : FLT_MAX;
+  struct Raw { float a, b; };
+  __device__ __forceinline__ Raw fetch(int64_t i) const {
+    Raw r;
+    r.a = num[i];
+    r.b = den != nullptr ? den[i] : 1.0f;
+    return r;
+  }
+  __device__ __forceinline__ float finish(const Raw &r) const {
+    if (den == nullptr) return r.a;
+    return r.b != 0.0f ? r.a / r.b : FLT_MAX;
   }
 };
 template <typename TI>
 struct ValRaw {
   const TI *img;
-  __device__ __forceinline__ float ld(int64_t i) const { return (float)img[i]; }
+  struct Raw { TI v; };
+  __device__ __forceinline__ Raw fetch(int64_t i) const { return Raw{img[i]}; }
+  __device__ __forceinline__ float finish(const Raw &r) const { return (float)r.v; }
 };
 
 __device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
@@ -183,19 +193,19 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
   const bool mine = mvec && tid < MT_DW && mx < g.nx && my < g.ny;
   const int64_t moff = (int64_t)mx + (int64_t)g.nx * my;  // element offset inside a plane
 
-  float r[FT_NLD];
+  typename VAL::Raw r[FT_NLD];
   uint32_t mr = 0;
   auto load_plane = [&](int p) {
     const int64_t pb = (int64_t)clampi(p + g.zoff, g.zc_hi) * g.plane;
 #pragma unroll
     for (int k = 0; k < FT_NLD; ++k)
-      if (has[k]) r[k] = val.ld(pb + off[k]);
+      if (has[k]) r[k] = val.fetch(pb + off[k]);
   };
   auto store_plane = [&](int p) {
     float *t = &tile[(p - (z0 - 1)) & 3][0][0];
 #pragma unroll
     for (int k = 0; k < FT_NLD; ++k)
-      if (has[k]) t[eidx[k]] = r[k];
+      if (has[k]) t[eidx[k]] = val.finish(r[k]);
   };
 
   load_plane(z0 - 1);
@@ -224,7 +234,9 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
     float o[NOUT];
 #pragma unroll
     for (int k = 0; k < NOUT; ++k) o[k] = 0.0f;
-    if (keep) {
+    // A wave whose 64 voxels are all outside the mask skips the arithmetic (scalar branch);
+    // otherwise every lane computes and masked lanes are zeroed at the end.
+    if (__builtin_amdgcn_ballot_w64(keep) != 0) {
       const float(*tm)[FT_HX] = tile[(z - 1 - (z0 - 1)) & 3];
       const float(*t0)[FT_HX] = tile[(z - (z0 - 1)) & 3];
       const float(*tp)[FT_HX] = tile[(z + 1 - (z0 - 1)) & 3];
@@ -299,6 +311,10 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
           }
         }
       }
+    }
+    if (!keep) {
+#pragma unroll
+      for (int k = 0; k < NOUT; ++k) o[k] = 0.0f;
     }
     if (planar) {
 #pragma unroll
