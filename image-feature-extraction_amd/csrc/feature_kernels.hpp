@@ -215,9 +215,35 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
   load_plane(z0 + 1);
   if (mine) mr = *reinterpret_cast<const uint32_t *>(mask + (int64_t)z0 * g.plane + moff);
 
+  // The outputs of plane z are stored at the top of iteration z+1, after that iteration's
+  // wait for its staged loads: the wait (vmcnt counts loads and stores in order) then never
+  // sits behind stores that were issued a moment ago.
+  float po[NOUT];
+  int64_t pidx = -1;
+  auto flush = [&]() {
+    if (pidx < 0) return;
+    if (planar) {
+#pragma unroll
+      for (int k = 0; k < NOUT; ++k) out[(int64_t)k * g.nvox + pidx] = po[k];
+    } else if constexpr (NOUT == 8) {
+      float4 *q = reinterpret_cast<float4 *>(out + pidx * 8);
+      q[0] = make_float4(po[0], po[1], po[2], po[3]);
+      q[1] = make_float4(po[4], po[5], po[6], po[7]);
+    } else if constexpr (NOUT == 6) {
+      float2 *q = reinterpret_cast<float2 *>(out + pidx * 6);
+      q[0] = make_float2(po[0], po[1]);
+      q[1] = make_float2(po[2], po[3]);
+      q[2] = make_float2(po[4], po[5]);
+    } else {
+      out[pidx] = po[0];
+    }
+  };
+
   for (int z = z0; z < z1; ++z) {
     store_plane(z + 1);
     if (mine) mtile[z & 1][tid] = mr;
+    flush();
+    pidx = -1;
     if (z + 1 < z1) {  // issue the next step's loads before consuming this one
       load_plane(z + 2);
       if (mine) mr = *reinterpret_cast<const uint32_t *>(mask + (int64_t)(z + 1) * g.plane + moff);
@@ -316,22 +342,11 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
 #pragma unroll
       for (int k = 0; k < NOUT; ++k) o[k] = 0.0f;
     }
-    if (planar) {
 #pragma unroll
-      for (int k = 0; k < NOUT; ++k) out[(int64_t)k * g.nvox + idx] = o[k];
-    } else if constexpr (NOUT == 8) {
-      float4 *q = reinterpret_cast<float4 *>(out + idx * 8);
-      q[0] = make_float4(o[0], o[1], o[2], o[3]);
-      q[1] = make_float4(o[4], o[5], o[6], o[7]);
-    } else if constexpr (NOUT == 6) {
-      float2 *q = reinterpret_cast<float2 *>(out + idx * 6);
-      q[0] = make_float2(o[0], o[1]);
-      q[1] = make_float2(o[2], o[3]);
-      q[2] = make_float2(o[4], o[5]);
-    } else {
-      out[idx] = o[0];
-    }
+    for (int k = 0; k < NOUT; ++k) po[k] = o[k];
+    pidx = idx;
   }
+  flush();
 }
 
 // ---- per-voxel numerics on a flat batch (a1 / a2 parity hooks) -----------------------
