@@ -365,8 +365,17 @@ __global__ __launch_bounds__(256) void iir_strided_kernel(IirJobs jobs, IirGeom 
       q2 = src.ld(B, voff, sst);
       q1 = src.ld(B, voff, 2u * sst);
     };
+    // checkpoint of the current pair and, in flight, of the next one: all loads of an
+    // iteration are issued before its stores, so the wait for them (vmcnt counts in
+    // order) can leave the 2K stores of the iteration outstanding
+    CausalState sc, sn;
+    sc.y1 = sc.y2 = sc.y3 = sc.y4 = 0.0;
+    sn = sc;
     load_pair(np - 1, xa, xb, true);
-    if (np > 1) load_hist(np - 1, h1, h2, h3);
+    if (np > 1) {
+      load_hist(np - 1, h1, h2, h3);
+      ck_load(ck, np - 1, nl, Lw, live ? lane : 0u, sc);
+    }
     {
       // x[n-1]: the clamped loads make every slot past the line end hold it
       const double xN = (double)xb[K - 1];
@@ -377,11 +386,14 @@ __global__ __launch_bounds__(256) void iir_strided_kernel(IirJobs jobs, IirGeom 
       const int64_t i0 = 2 * p * K, i1 = i0 + K;
       if (p > 0) {
         load_pair(p - 1, na, nb2, false);
-        if (p > 1) load_hist(p - 1, nh1, nh2, nh3);
+        if (p > 1) {
+          load_hist(p - 1, nh1, nh2, nh3);
+          ck_load(ck, p - 1, nl, Lw, live ? lane : 0u, sn);
+        }
       }
       CausalState s0;
       if (p > 0) {
-        ck_load(ck, p, nl, Lw, live ? lane : 0u, s0);
+        s0.y1 = sc.y1; s0.y2 = sc.y2; s0.y3 = sc.y3; s0.y4 = sc.y4;
         s0.x1 = (double)h1; s0.x2 = (double)h2; s0.x3 = (double)h3;
       } else {
         const double x0 = (double)xa[0];
@@ -418,6 +430,7 @@ __global__ __launch_bounds__(256) void iir_strided_kernel(IirJobs jobs, IirGeom 
 #pragma unroll
       for (int j = 0; j < K; ++j) { xa[j] = na[j]; xb[j] = nb2[j]; }
       h1 = nh1; h2 = nh2; h3 = nh3;
+      sc.y1 = sn.y1; sc.y2 = sn.y2; sc.y3 = sn.y3; sc.y4 = sn.y4;
     }
   }
 }
