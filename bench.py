@@ -161,8 +161,18 @@ def main():
     alg_bytes_step_rank = ALG_BYTES_PER_VOXEL_SCALE * (nvox / world) * len(sigmas)
     achieved = alg_bytes_step_rank / (dev_ms_step * 1e-3) / 1e9 if dev_ms_step > 0 else 0.0
     dominant = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
+    # HBM bytes per step from the committed PMC passes (profiles/, same default workload);
+    # PMC counters cannot be collected from inside this process
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    default_cfg = (world == 1 and [nz, ny, nx] == [512, 512, 512] and sigmas == [1.0, 2.0, 4.0]
+                   and args.mask == "ones" and args.layout == "interleaved" and args.trig == 0)
+    if default_cfg and os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("traffic_bytes_per_step")
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": "profiles/r01_traffic.json (rocprofv3 PMC, bytes per step)"
+                if traffic else None,
                 "scope": "all kernels of one step (sum of hipEvent durations %.3f ms); "
                          "algorithmic bytes = 37 B x voxels x scales" % dev_ms_step,
                 "dominant_kernel": dominant, "kernels": kern}
