@@ -45,6 +45,8 @@ def parse():
                     help="ones: explicit all-ones uint8 mask (every voxel pays the full path); "
                          "ellipsoids: ~20%% foreground like a lung mask")
     ap.add_argument("--layout", choices=["interleaved", "planar"], default="interleaved")
+    ap.add_argument("--spacing", type=float, nargs=3, default=[1.0, 1.0, 1.0], metavar=("SX", "SY", "SZ"))
+    ap.add_argument("--i16", action="store_true", help="int16 CT-like input (BASELINE configs[4])")
     ap.add_argument("--trig", type=int, default=0)
     ap.add_argument("--iir-block", type=int, default=None)
     ap.add_argument("--zchunk", type=int, default=None)
@@ -166,7 +168,8 @@ def main():
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
     default_cfg = (world == 1 and [nz, ny, nx] == [512, 512, 512] and sigmas == [1.0, 2.0, 4.0]
-                   and args.mask == "ones" and args.layout == "interleaved" and args.trig == 0)
+                   and args.mask == "ones" and args.layout == "interleaved" and args.trig == 0
+                   and not args.i16 and list(args.spacing) == [1.0, 1.0, 1.0])
     if default_cfg and os.path.exists(tpath):
         traffic = json.load(open(tpath)).get("traffic_bytes_per_step")
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -185,8 +188,11 @@ def main():
         "dtype": "f32 storage / f64 line recurrences", "data": "synthetic",
         "config": {"workload": "%dx%dx%d float32 volume, sigma=%s, 8 features/voxel/scale "
                                "(ImageToEmphysemaFeaturesFilter), uint8 mask=%s, %s output, "
-                               "%s" % (nx, ny, nz, sigmas, args.mask, args.layout,
-                                       "1 GPU" if world == 1 else "%d Z-slabs" % world),
+                               "%s%s" % (nx, ny, nz, sigmas, args.mask, args.layout,
+                                         "1 GPU" if world == 1 else "%d Z-slabs" % world,
+                                         (", int16 input" if args.i16 else "")
+                                         + ("" if list(args.spacing) == [1.0, 1.0, 1.0]
+                                            else ", spacing %s" % list(args.spacing))),
                    "trig_mode": args.trig},
         "roofline": roofline,
     }
@@ -202,8 +208,9 @@ class SingleGpuRunner:
     def __init__(self, pkg, synth, shape, sigmas, seed, mask_kind, layout, dev, args):
         import torch
         self.pkg, self.shape, self.sigmas, self.layout = pkg, shape, sigmas, layout
+        self.i16, self.spacing = args.i16, tuple(args.spacing)
         nz, ny, nx = shape
-        img = synth.volume_f32(shape, seed)
+        img = synth.volume_i16(shape, seed) if args.i16 else synth.volume_f32(shape, seed)
         if mask_kind == "ellipsoids":
             mask = np.minimum(synth.mask_ellipsoids(shape), 1).astype(np.uint8)
         else:
@@ -224,8 +231,8 @@ class SingleGpuRunner:
 
     def step(self):
         self.ctx.emphysema_features_device(
-            self.d_img.data_ptr(), self.pkg.F32, self.mask_ptr, self.pkg.U8, self.shape,
-            (1.0, 1.0, 1.0), self.sigmas, self.d_out.data_ptr(), self.layout)
+            self.d_img.data_ptr(), self.pkg.I16 if self.i16 else self.pkg.F32, self.mask_ptr,
+            self.pkg.U8, self.shape, self.spacing, self.sigmas, self.d_out.data_ptr(), self.layout)
 
 
 if __name__ == "__main__":

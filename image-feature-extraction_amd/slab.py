@@ -64,6 +64,9 @@ class TorchComm:
 
     def __init__(self, dist, rank, world, host_staging=False):
         self.dist, self.rank, self.world, self.host = dist, rank, world, host_staging
+        # The halo planes travel on their own communicator: on the default one they would
+        # queue behind the all-to-alls of the later scales, which are issued up front.
+        self.halo_group = dist.new_group(list(range(world))) if world > 1 else None
 
     def all_to_all(self, send, recv, async_op=False):
         """send/recv: contiguous [world, ...]; chunk h of send goes to rank h."""
@@ -94,11 +97,12 @@ class TorchComm:
             lo_b, hi_b = lo_halo.cpu(), hi_halo.cpu()
         else:
             fp, lp, lo_b, hi_b = first_plane, last_plane, lo_halo, hi_halo
+        g = self.halo_group
         if lo >= 0:
-            ops += [dist.P2POp(dist.isend, fp, lo), dist.P2POp(dist.irecv, lo_b, lo)]
+            ops += [dist.P2POp(dist.isend, fp, lo, group=g), dist.P2POp(dist.irecv, lo_b, lo, group=g)]
             post.append((lo_halo, lo_b))
         if hi < self.world:
-            ops += [dist.P2POp(dist.isend, lp, hi), dist.P2POp(dist.irecv, hi_b, hi)]
+            ops += [dist.P2POp(dist.isend, lp, hi, group=g), dist.P2POp(dist.irecv, hi_b, hi, group=g)]
             post.append((hi_halo, hi_b))
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
