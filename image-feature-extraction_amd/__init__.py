@@ -93,10 +93,10 @@ def load_library():
     lib.ife_fd_hessian_features.argtypes = [vp, vp, i32, vp, i32, vd, f32p, i32, i32]
     lib.ife_fd_gradient_features.argtypes = [vp, f32p, f32p, vd, f32p, i32]
     lib.ife_mask_image_f64.argtypes = [vp, vp, vp, C.c_double, i64, vp, i32]
-    lib.ife_stage_prepare.argtypes = [vp, vp, i32, vp, i32, i64, vp, vp]
+    lib.ife_stage_prepare.argtypes = [vp, vp, i32, vp, i32, vd, i32, vp, vp]
     lib.ife_stage_recursive_gaussian.argtypes = [vp, vp, vp, vd, i32, C.c_double]
     lib.ife_stage_recursive_gaussian_batch.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), vd,
-                                                       i32, C.POINTER(C.c_double)]
+                                                       i32, C.POINTER(C.c_double), i32]
     lib.ife_stage_features.argtypes = [vp, vp, vp, vp, i32, vd, i32, i32, vp, i32]
     lib.ife_get_kernel_times.argtypes = [vp, C.POINTER(KernelTime), i32]
     lib.ife_reset_kernel_times.argtypes = [vp]
@@ -290,10 +290,12 @@ class Context:
             C.byref(d), C.c_void_p(out_ptr), layout, MEM_DEVICE))
 
     # ---- stage entry points (device pointers; Z-slab orchestration, slab.py) ------------
-    def stage_prepare(self, image_ptr, image_dtype, mask_ptr, mask_dtype, n, tc_ptr, cf_ptr):
+    def stage_prepare(self, image_ptr, image_dtype, mask_ptr, mask_dtype, slab_shape_zyx, tc_ptr,
+                      cf_ptr, y_chunks=1):
+        d = _desc(slab_shape_zyx, (1.0, 1.0, 1.0))
         self._chk(self._lib.ife_stage_prepare(
             self._h, C.c_void_p(image_ptr), image_dtype, C.c_void_p(mask_ptr or 0), mask_dtype,
-            int(n), C.c_void_p(tc_ptr), C.c_void_p(cf_ptr or 0)))
+            C.byref(d), int(y_chunks), C.c_void_p(tc_ptr), C.c_void_p(cf_ptr or 0)))
 
     def stage_recursive_gaussian(self, in_ptr, out_ptr, shape_zyx, spacing, axis_xyz, sigma):
         d = _desc(shape_zyx, spacing)
@@ -302,7 +304,7 @@ class Context:
             float(sigma)))
 
     def stage_recursive_gaussian_batch(self, in_ptrs, out_ptrs, shape_zyx, spacing, axis_xyz,
-                                       sigmas):
+                                       sigmas, in_y_chunks=1):
         """One launch over len(in_ptrs) float volumes of the same shape (<= 8 jobs)."""
         n = len(in_ptrs)
         d = _desc(shape_zyx, spacing)
@@ -310,7 +312,7 @@ class Context:
         outs = (C.c_void_p * n)(*out_ptrs)
         sg = (C.c_double * n)(*[float(s) for s in sigmas])
         self._chk(self._lib.ife_stage_recursive_gaussian_batch(
-            self._h, n, ins, outs, C.byref(d), int(axis_xyz), sg))
+            self._h, n, ins, outs, C.byref(d), int(axis_xyz), sg, int(in_y_chunks)))
 
     def stage_features(self, num_ptr, den_ptr, mask_ptr, mask_dtype, slab_shape_zyx, spacing,
                        halo_lo, halo_hi, out_ptr, layout=INTERLEAVED):

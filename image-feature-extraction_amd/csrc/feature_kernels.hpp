@@ -386,11 +386,25 @@ __global__ __launch_bounds__(256) void mask_f64_kernel(const double *__restrict_
 // byte loads was measured at ~64 cycles in the TA): here every lane moves 4 voxels
 // with one vector load per input, and the line kernels then only read floats.
 // msk == nullptr: tc = float(image) only.  cf == nullptr: not written.
+// Output placement: plain (chunks <= 1), or the Y-chunked order [chunks][nz][ny/chunks][nx]
+// an all-to-all sends from (chunk h = rows of the Y-slab of rank h), so that a slab host
+// needs no separate packing pass.
+struct PrepGeom {
+  int64_t nx, ny, nz;
+  int64_t chunks, nyl;  // nyl = ny / chunks
+};
+__device__ __forceinline__ int64_t prep_out_index(const PrepGeom &g, int64_t i) {
+  if (g.chunks <= 1) return i;
+  const int64_t x = i % g.nx, y = (i / g.nx) % g.ny, z = i / (g.nx * g.ny);
+  const int64_t h = y / g.nyl, yy = y % g.nyl;
+  return ((h * g.nz + z) * g.nyl + yy) * g.nx + x;
+}
 template <typename TI, typename TM>
 __global__ __launch_bounds__(256) void prep_kernel_vec4(const TI *__restrict__ img,
                                                         const TM *__restrict__ msk,
                                                         float *__restrict__ tc,
-                                                        float *__restrict__ cf, int64_t n4) {
+                                                        float *__restrict__ cf, int64_t n4,
+                                                        PrepGeom g) {
   typedef TI TI4 __attribute__((ext_vector_type(4)));
   typedef TM TM4 __attribute__((ext_vector_type(4)));
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -398,13 +412,14 @@ __global__ __launch_bounds__(256) void prep_kernel_vec4(const TI *__restrict__ i
   for (; i < n4; i += stride) {
     const TI4 a = reinterpret_cast<const TI4 *>(img)[i];
     float4 t = make_float4((float)a.x, (float)a.y, (float)a.z, (float)a.w);
+    const int64_t o = prep_out_index(g, 4 * i) / 4;  // nx % 4 == 0 on this path
     if (msk != nullptr) {
       const TM4 m = reinterpret_cast<const TM4 *>(msk)[i];
       const float4 c = make_float4((float)m.x, (float)m.y, (float)m.z, (float)m.w);
       t.x *= c.x; t.y *= c.y; t.z *= c.z; t.w *= c.w;
-      if (cf != nullptr) reinterpret_cast<float4 *>(cf)[i] = c;
+      if (cf != nullptr) reinterpret_cast<float4 *>(cf)[o] = c;
     }
-    reinterpret_cast<float4 *>(tc)[i] = t;
+    reinterpret_cast<float4 *>(tc)[o] = t;
   }
 }
 template <typename TI, typename TM>
@@ -412,17 +427,18 @@ __global__ __launch_bounds__(256) void prep_kernel_scalar(const TI *__restrict__
                                                           const TM *__restrict__ msk,
                                                           float *__restrict__ tc,
                                                           float *__restrict__ cf, int64_t i0,
-                                                          int64_t n) {
+                                                          int64_t n, PrepGeom g) {
   int64_t i = i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
     float t = (float)img[i];
+    const int64_t o = prep_out_index(g, i);
     if (msk != nullptr) {
       const float c = (float)msk[i];
       t *= c;
-      if (cf != nullptr) cf[i] = c;
+      if (cf != nullptr) cf[o] = c;
     }
-    tc[i] = t;
+    tc[o] = t;
   }
 }
 

@@ -235,6 +235,7 @@ DerivCoef deriv_coeffs(const ife_volume_desc *v, int dscale_mode) {
 
 IirGeom geom_for_axis(const ife_volume_desc *v, int axis) {
   IirGeom g;
+  g.in_w = 0; g.in_group = 0; g.in_nz = 0;
   const int64_t nx = v->nx, ny = v->ny, nz = v->nz;
   if (axis == 2) {
     g.n = nz; g.nlines = nx * ny; g.sstride = nx * ny; g.inner = nx * ny; g.outer = 0;
@@ -278,9 +279,18 @@ int ensure_slots(ife_ctx *ctx, const ife_volume_desc *v, int nslots) {
 // One launch of the line kernel along `axis` over njobs independent float volumes
 // (jobs = numerator / denominator of up to three scales), each with its own sigma.
 int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
-               const float *const *in, float *const *out, const double *sigma) {
+               const float *const *in, float *const *out, const double *sigma,
+               int in_y_chunks = 1) {
   if (njobs < 1 || njobs > IIR_MAX_JOBS) return fail(ctx, IFE_E_ARG, "bad job count %d", njobs);
-  const IirGeom g = geom_for_axis(v, axis);
+  IirGeom g = geom_for_axis(v, axis);
+  if (in_y_chunks > 1) {
+    if (axis != 0) return fail(ctx, IFE_E_ARG, "Y-chunked input is only read by the x pass");
+    if (v->ny % in_y_chunks || (v->ny / in_y_chunks) % 64)
+      return fail(ctx, IFE_E_SIZE, "Y-chunked input needs ny/chunks to be a multiple of 64");
+    g.in_w = in_y_chunks;
+    g.in_group = v->ny / in_y_chunks;
+    g.in_nz = v->nz;
+  }
   // 32-bit offsets of the buffer accesses (iir_kernels.hpp "addressing")
   if ((int64_t)2 * ctx->iir_block * g.sstride * 4 >= (int64_t)1 << 31 ||
       g.outer * 4 >= (int64_t)1 << 32 || g.nlines * 8 * 3 >= (int64_t)1 << 32)
@@ -317,23 +327,25 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
 }
 
 template <typename TI, typename TM>
-int launch_prep(ife_ctx *ctx, const TI *img, const TM *msk, float *tc, float *cf, int64_t n) {
+int launch_prep(ife_ctx *ctx, const TI *img, const TM *msk, float *tc, float *cf, int64_t n,
+                PrepGeom pg = PrepGeom{0, 0, 0, 0, 0}) {
   ProfScope ps(ctx, KK_PREP);
   const uintptr_t al = reinterpret_cast<uintptr_t>(img) % (4 * sizeof(TI)) |
                        reinterpret_cast<uintptr_t>(msk) % (4 * sizeof(TM)) |
                        reinterpret_cast<uintptr_t>(tc) % 16 | reinterpret_cast<uintptr_t>(cf) % 16;
-  const int64_t n4 = al == 0 ? n / 4 : 0;
+  const bool vec = al == 0 && (pg.chunks <= 1 || pg.nx % 4 == 0);
+  const int64_t n4 = vec ? n / 4 : 0;
   if (n4 > 0) {
     const unsigned blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, 8192);
     hipLaunchKernelGGL((prep_kernel_vec4<TI, TM>), dim3(blocks), dim3(256), 0, ctx->stream, img,
-                       msk, tc, cf, n4);
+                       msk, tc, cf, n4, pg);
     IFE_HIP(ctx, hipGetLastError());
   }
   if (n4 * 4 < n) {
     const int64_t rest = n - n4 * 4;
     const unsigned blocks = (unsigned)std::min<int64_t>((rest + 255) / 256, 8192);
     hipLaunchKernelGGL((prep_kernel_scalar<TI, TM>), dim3(blocks), dim3(256), 0, ctx->stream,
-                       img, msk, tc, cf, n4 * 4, n);
+                       img, msk, tc, cf, n4 * 4, n, pg);
     IFE_HIP(ctx, hipGetLastError());
   }
   return IFE_OK;
@@ -805,20 +817,26 @@ int ife_mask_image_f64(ife_ctx *ctx, const double *image, const double *mask, do
 
 // ---- stage entry points (device pointers only; Z-slab orchestration) --------------------
 int ife_stage_prepare(ife_ctx *ctx, const void *image, int image_dtype, const void *mask,
-                      int mask_dtype, int64_t n, float *tc, float *cf) {
+                      int mask_dtype, const ife_volume_desc *slab, int y_chunks, float *tc,
+                      float *cf) {
   int rc = bind(ctx);
   if (rc) return rc;
-  if (!image || !tc || n <= 0) return fail(ctx, IFE_E_ARG, "null pointer or empty volume");
+  if ((rc = check_vol(ctx, slab, false))) return rc;
+  if (!image || !tc) return fail(ctx, IFE_E_ARG, "null pointer");
   if (image_dtype != IFE_F32 && image_dtype != IFE_I16)
     return fail(ctx, IFE_E_ARG, "image dtype must be IFE_F32 or IFE_I16");
   if (mask && mask_dtype != IFE_U8 && mask_dtype != IFE_U16)
     return fail(ctx, IFE_E_ARG, "mask dtype must be IFE_U8 or IFE_U16");
+  if (y_chunks < 1 || slab->ny % y_chunks)
+    return fail(ctx, IFE_E_SIZE, "ny must be a multiple of the number of Y chunks");
+  const int64_t n = slab->nx * slab->ny * slab->nz;
+  const PrepGeom pg{slab->nx, slab->ny, slab->nz, y_chunks, slab->ny / y_chunks};
   const bool u16 = mask && mask_dtype == IFE_U16;
   if (image_dtype == IFE_F32)
-    return u16 ? launch_prep(ctx, (const float *)image, (const uint16_t *)mask, tc, cf, n)
-               : launch_prep(ctx, (const float *)image, (const uint8_t *)mask, tc, cf, n);
-  return u16 ? launch_prep(ctx, (const int16_t *)image, (const uint16_t *)mask, tc, cf, n)
-             : launch_prep(ctx, (const int16_t *)image, (const uint8_t *)mask, tc, cf, n);
+    return u16 ? launch_prep(ctx, (const float *)image, (const uint16_t *)mask, tc, cf, n, pg)
+               : launch_prep(ctx, (const float *)image, (const uint8_t *)mask, tc, cf, n, pg);
+  return u16 ? launch_prep(ctx, (const int16_t *)image, (const uint16_t *)mask, tc, cf, n, pg)
+             : launch_prep(ctx, (const int16_t *)image, (const uint8_t *)mask, tc, cf, n, pg);
 }
 
 int ife_stage_recursive_gaussian(ife_ctx *ctx, const float *in, float *out,
@@ -841,7 +859,7 @@ int ife_stage_recursive_gaussian(ife_ctx *ctx, const float *in, float *out,
 
 int ife_stage_recursive_gaussian_batch(ife_ctx *ctx, int njobs, const float *const *in,
                                        float *const *out, const ife_volume_desc *vol, int axis,
-                                       const double *sigmas) {
+                                       const double *sigmas, int in_y_chunks) {
   int rc = bind(ctx);
   if (rc) return rc;
   if ((rc = check_vol(ctx, vol, false))) return rc;
@@ -853,7 +871,7 @@ int ife_stage_recursive_gaussian_batch(ife_ctx *ctx, int njobs, const float *con
   if (len < 4)
     return fail(ctx, IFE_E_SIZE, "the recursive Gaussian needs at least 4 voxels along axis %d",
                 axis);
-  return launch_iir(ctx, vol, axis, njobs, in, out, sigmas);
+  return launch_iir(ctx, vol, axis, njobs, in, out, sigmas, in_y_chunks);
 }
 
 int ife_stage_features(ife_ctx *ctx, const float *num, const float *den, const void *mask,

@@ -45,6 +45,11 @@ struct IirGeom {
   int64_t sstride;  // element stride between consecutive samples of a line
   int64_t inner;    // strided: lines per contiguous row (line L -> base (L%inner)+(L/inner)*outer)
   int64_t outer;    // strided: element stride between rows of lines; contig: line pitch
+  // contiguous-axis kernel only: the INPUT may be the Y-chunked image of a Z-slab as an
+  // all-to-all leaves it, [in_w][nz][in_group][nx] (chunk h holds rows h*in_group ..), while
+  // the output is the plain [nz][ny][nx] slab.  in_w <= 1: plain input.  Needs 64 | in_group
+  // so that the 64 lines of a wave stay contiguous.
+  int64_t in_w, in_group, in_nz;
 };
 
 struct CausalState {
@@ -565,7 +570,12 @@ __global__ __launch_bounds__(256, 2) void iir_contig_kernel(IirJobs jobs, IirGeo
                       ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
                       (pitch * 64 * 4 < (int64_t)0x7fffffff);
   const bool live = (int64_t)lane < nrows;
-  const float *rows_in = in + line0 * pitch;
+  int64_t in_line0 = line0;
+  if (g.in_w > 1) {
+    const int64_t gi = line0 / g.in_group, within = line0 % g.in_group;  // gi = z*in_w + h
+    in_line0 = ((gi % g.in_w) * g.in_nz + gi / g.in_w) * g.in_group + within;
+  }
+  const float *rows_in = in + in_line0 * pitch;
   float *rows_out = out + line0 * pitch;
 
   float xb[K];

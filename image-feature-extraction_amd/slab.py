@@ -37,19 +37,22 @@ class HipStages:
     def __init__(self, pkg, ctx):
         self.pkg, self.ctx = pkg, ctx
 
-    def prepare(self, img, mask, tc, cf):
+    def prepare(self, img, mask, tc, cf, y_chunks):
+        """tc/cf are written in all-to-all send order [y_chunks][nzl][ny/y_chunks][nx]."""
         pkg = self.pkg
         idt = pkg.F32 if img.element_size() == 4 else pkg.I16
         mdt = pkg.U8 if mask is None or mask.element_size() == 1 else pkg.U16
         self.ctx.stage_prepare(img.data_ptr(), idt, mask.data_ptr() if mask is not None else None,
-                               mdt, img.numel(), tc.data_ptr(),
-                               cf.data_ptr() if cf is not None else None)
+                               mdt, tuple(img.shape), tc.data_ptr(),
+                               cf.data_ptr() if cf is not None else None, y_chunks)
 
-    def gaussian_axis_batch(self, srcs, dsts, spacing, axis, sigmas):
-        """One launch over several float volumes of the same shape (jobs)."""
+    def gaussian_axis_batch(self, srcs, dsts, spacing, axis, sigmas, in_y_chunks=1):
+        """One launch over several float volumes (jobs) shaped like dsts[0].  With
+        in_y_chunks = W the sources are [W][nzl][ny/W][nx] as an all-to-all left them."""
         self.ctx.stage_recursive_gaussian_batch([t.data_ptr() for t in srcs],
                                                 [t.data_ptr() for t in dsts],
-                                                tuple(srcs[0].shape), spacing, axis, sigmas)
+                                                tuple(dsts[0].shape), spacing, axis, sigmas,
+                                                in_y_chunks)
 
     def features(self, num, den, mask, slab_shape, spacing, halo_lo, halo_hi, out, layout):
         mdt = self.pkg.U8 if mask is None or mask.element_size() == 1 else self.pkg.U16
@@ -132,23 +135,15 @@ class SlabEngine:
         nf = 2 if has_mask else 1
         S = len(self.sigmas)
         self.group = 4 if nf == 2 else 8              # scales per line-kernel launch (<= 8 jobs)
-        self.src_z = [f(nzl, ny, nx) for _ in range(nf)]          # tc, cf (Z-slab)
-        self.pack = f(W, nzl, nyl, nx)                            # all-to-all staging
+        if nyl % 64 and world > 1:
+            raise ValueError("ny/world = %d must be a multiple of 64 (wave-aligned Y chunks)" % nyl)
+        self.src_z = [f(W, nzl, nyl, nx) for _ in range(nf)]      # tc, cf in send order
         self.src_y = [f(W, nzl, nyl, nx) for _ in range(nf)]      # tc, cf (Y-slab == [nz][nyl][nx])
-        # per scale: Z-pass output (Y-slab) and its Z-slab image after exchange #1
+        # per scale: Z-pass output (Y-slab) and its Y-chunked Z-slab image after exchange #1
         self.zy = [[f(W, nzl, nyl, nx) for _ in range(nf)] for _ in range(S)]
         self.zz = [[f(W, nzl, nyl, nx) for _ in range(nf)] for _ in range(S)]
-        self.a = [f(nzl, ny, nx) for _ in range(nf)]              # unpacked Z-pass output
         self.b = [f(nzl, ny, nx) for _ in range(nf)]              # X-pass output
         self.pad = [f(nzl + 2, ny, nx) for _ in range(nf)]        # Y-pass output + halo planes
-
-    # Z-slab [nzl][ny][nx] -> chunks by destination rank [W][nzl][nyl][nx]
-    def _pack_z(self, vol, dst):
-        dst.copy_(vol.view(self.nzl, self.W, self.nyl, self.nx).permute(1, 0, 2, 3))
-
-    # received chunks by source Y-range [W][nzl][nyl][nx] -> Z-slab [nzl][ny][nx]
-    def _unpack_z(self, chunks, vol):
-        vol.view(self.nzl, self.W, self.nyl, self.nx).copy_(chunks.permute(1, 0, 2, 3))
 
     def run(self, img_slab, mask_slab, out):
         """img_slab [nzl][ny][nx] f32|i16, mask_slab same shape u8|u16 or None,
@@ -158,11 +153,11 @@ class SlabEngine:
         yshape = (self.nz, self.nyl, self.nx)
         sp = self.spacing
         S = len(self.sigmas)
+        # Cast + Multiply, written straight in send order; exchange #0
         st.prepare(img_slab, mask_slab if self.has_mask else None, self.src_z[0],
-                   self.src_z[1] if self.has_mask else None)
-        for k in range(nf):                                   # exchange #0
-            self._pack_z(self.src_z[k], self.pack)
-            comm.all_to_all(self.pack, self.src_y[k])
+                   self.src_z[1] if self.has_mask else None, self.W)
+        for k in range(nf):
+            comm.all_to_all(self.src_z[k], self.src_y[k])
         # Z pass of every scale and field in as few launches as possible (a slab has few
         # lines; one job per launch would leave most of the device idle), then all the
         # exchanges #1 back to back: those of scale s+1.. travel while scale s computes.
@@ -180,10 +175,9 @@ class SlabEngine:
             for w in pending[s]:
                 if w is not None:
                     w.wait()
-            for k in range(nf):
-                self._unpack_z(self.zz[s][k], self.a[k])
             sg = [self.sigmas[s]] * nf
-            st.gaussian_axis_batch(self.a[:nf], self.b[:nf], sp, 0, sg)
+            # the x pass reads the Y-chunked buffers the exchange left and writes plain slabs
+            st.gaussian_axis_batch(self.zz[s][:nf], self.b[:nf], sp, 0, sg, self.W)
             st.gaussian_axis_batch(self.b[:nf], [p[1:self.nzl + 1] for p in self.pad[:nf]], sp, 1, sg)
             for k in range(nf):                               # exchange #2
                 p = self.pad[k]

@@ -183,10 +183,14 @@ int ife_mask_image_f64(ife_ctx *ctx, const double *image, const double *mask, do
  * stream and do not synchronise. */
 
 /* CastImageFilter + MultiplyImageFilter (ImageToEmphysemaFeaturesFilter.hxx:21,110;
- * NormalizedGaussianConvolutionImageFilter.hxx:48-49): tc = float(image)*float(mask),
- * cf = float(mask).  mask NULL: tc = float(image), cf untouched (may be NULL). */
+ * NormalizedGaussianConvolutionImageFilter.hxx:48-49) on a slab: tc = float(image) *
+ * float(mask), cf = float(mask).  mask NULL: tc = float(image), cf untouched (may be NULL).
+ * y_chunks = 1: outputs in the slab's own order.  y_chunks = W > 1: outputs in the order an
+ * all-to-all sends from, [W][nz][ny/W][nx] (chunk h = the rows of rank h's Y-slab), so the
+ * host needs no packing pass. */
 int ife_stage_prepare(ife_ctx *ctx, const void *image, int image_dtype, const void *mask,
-                      int mask_dtype, int64_t n, float *tc, float *cf);
+                      int mask_dtype, const ife_volume_desc *slab, int y_chunks, float *tc,
+                      float *cf);
 /* One axis of itk::SmoothingRecursiveGaussianImageFilter (the reference reaches it at
  * NormalizedGaussianConvolutionImageFilter.hxx:51-55); axis 0 = x, 1 = y, 2 = z; the
  * caller keeps ITK's order z, x, y.  Not in place. */
@@ -194,10 +198,13 @@ int ife_stage_recursive_gaussian(ife_ctx *ctx, const float *in, float *out,
                                  const ife_volume_desc *vol, int axis, double sigma);
 /* The same over njobs (<= 8) float volumes of one geometry in a single launch, each with
  * its own sigma: numerator and denominator of several scales.  A slab host needs this to
- * keep the device full (a 64-plane slab has too few lines for one job per launch). */
+ * keep the device full (a 64-plane slab has too few lines for one job per launch).
+ * in_y_chunks = W > 1 (axis 0 only): every input is the Y-chunked image of the slab as the
+ * all-to-all back from the Z pass leaves it, [W][nz][ny/W][nx]; the outputs are plain
+ * slabs.  Needs (ny/W) % 64 == 0.  in_y_chunks = 1: plain inputs. */
 int ife_stage_recursive_gaussian_batch(ife_ctx *ctx, int njobs, const float *const *in,
                                        float *const *out, const ife_volume_desc *vol, int axis,
-                                       const double *sigmas);
+                                       const double *sigmas, int in_y_chunks);
 /* Everything after the smoothing (ImageToEmphysemaFeaturesFilter.hxx:27-54 plus the
  * Divide of NormalizedGaussianConvolutionImageFilter.hxx:57-61) on a slab of slab->nz
  * planes.  num/den hold halo_lo + slab->nz + halo_hi planes: with halo_lo (halo_hi) = 1

@@ -32,19 +32,31 @@ class OracleStages:
     def __init__(self, oracle):
         self.o = oracle
 
-    def prepare(self, img, mask, tc, cf):
-        import torch
-        if mask is None:
-            tc.copy_(img.float())
-        else:
-            tc.copy_(img.float() * mask.float())
-            cf.copy_(mask.float())
+    @staticmethod
+    def _chunk(vol, W):
+        """[nzl][ny][nx] -> [W][nzl][ny/W][nx] (all-to-all send order)."""
+        nzl, ny, nx = vol.shape
+        return vol.reshape(nzl, W, ny // W, nx).permute(1, 0, 2, 3).contiguous()
 
-    def gaussian_axis_batch(self, srcs, dsts, spacing, axis, sigmas):
+    @staticmethod
+    def _unchunk(ch):
+        W, nzl, nyl, nx = ch.shape
+        return ch.permute(1, 0, 2, 3).contiguous().reshape(nzl, W * nyl, nx)
+
+    def prepare(self, img, mask, tc, cf, y_chunks):
+        if mask is None:
+            tc.copy_(self._chunk(img.float(), y_chunks))
+        else:
+            tc.copy_(self._chunk(img.float() * mask.float(), y_chunks))
+            cf.copy_(self._chunk(mask.float(), y_chunks))
+
+    def gaussian_axis_batch(self, srcs, dsts, spacing, axis, sigmas, in_y_chunks=1):
         import torch
         for src, dst, sigma in zip(srcs, dsts, sigmas):
+            a = self._unchunk(src) if in_y_chunks > 1 else src.contiguous()
+            a = a.reshape(tuple(dst.shape))
             dst.copy_(torch.from_numpy(
-                self.o.recursive_gaussian_axis(src.contiguous().numpy(), axis, sigma, spacing)))
+                self.o.recursive_gaussian_axis(a.numpy(), axis, sigma, spacing)))
 
     def features(self, num, den, mask, slab_shape, spacing, halo_lo, halo_hi, out, layout):
         import torch
@@ -125,8 +137,8 @@ def _whole_volume(synth, shape):
     return img, mask
 
 
-@pytest.mark.parametrize("world,shape,spacing", [(2, (16, 12, 20), (1.0, 1.0, 1.0)),
-                                                 (4, (16, 8, 9), (0.8, 1.0, 1.25))])
+@pytest.mark.parametrize("world,shape,spacing", [(2, (16, 128, 12), (1.0, 1.0, 1.0)),
+                                                 (4, (8, 256, 9), (0.8, 1.0, 1.25))])
 def test_slab_engine_equals_single_process_oracle(oracle, synth, tmp_path, world, shape, spacing):
     sigmas = [1.0, 2.0]
     got = _run_world(world, shape, sigmas, spacing, False, tmp_path)
@@ -140,12 +152,14 @@ def test_slab_engine_rejects_uneven_cuts(ife):
     slab = importlib.import_module(PKG + ".slab")
     with pytest.raises(ValueError):
         slab.SlabEngine(None, None, (10, 12, 8), (1, 1, 1), [1.0], 0, 4, lambda s: None, 0)
+    with pytest.raises(ValueError):  # Y chunks must be wave aligned
+        slab.SlabEngine(None, None, (8, 64, 8), (1, 1, 1), [1.0], 0, 2, lambda s: None, 0)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4])
 def test_slab_engine_on_gpu_equals_single_gpu(ife, synth, tmp_path, world):
-    shape, sigmas, spacing = (32, 24, 72), [1.0, 3.0], (1.0, 1.0, 1.0)
+    shape, sigmas, spacing = (32, 256, 40), [1.0, 3.0], (1.0, 1.0, 1.0)
     got = _run_world(world, shape, sigmas, spacing, True, tmp_path)
     img, mask = _whole_volume(synth, shape)
     with ife.Context(0) as c:
