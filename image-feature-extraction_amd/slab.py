@@ -21,9 +21,9 @@ is the one stage a Z-slab cut cannot keep local.  Re-cutting the two smoothing i
 along Y for that pass keeps the arithmetic exactly the sequential recursion of the
 single-GPU path (results are bit-identical to it), at the price of moving 8 B/voxel/scale
 across xGMI; each rank talks to all W-1 peers at once, so all seven links carry
-traffic.  The Z passes of all scales run first (batched into
-few launches, because a slab has few lines per field), then every scale's all-to-all is
-issued at once, so the exchanges of scales s+1.. travel while scale s computes.
+traffic.  The Z pass of scale 0 runs first and its exchange
+starts at once; the Z passes of the other scales run batched in one launch (a slab has few
+lines per field) behind it, and their exchanges travel while scale 0 computes.
 
 Nothing here touches the oracle: `stages` is the C-ABI (HipStages).  Tests substitute
 their own stage object to exercise this orchestration on CPU with gloo.
@@ -158,16 +158,20 @@ class SlabEngine:
                    self.src_z[1] if self.has_mask else None, self.W)
         for k in range(nf):
             comm.all_to_all(self.src_z[k], self.src_y[k])
-        # Z pass of every scale and field in as few launches as possible (a slab has few
-        # lines; one job per launch would leave most of the device idle), then all the
-        # exchanges #1 back to back: those of scale s+1.. travel while scale s computes.
-        for s0 in range(0, S, self.group):
-            ss = range(s0, min(S, s0 + self.group))
+        # Z passes and exchanges #1.  Scale 0 goes alone so that its exchange is on the wire
+        # while the remaining scales run their Z pass in ONE launch (a slab has few lines per
+        # field: one job per launch would leave most of the device idle); the exchanges of
+        # scales 1.. then travel while scale 0 runs its X/Y/feature kernels.
+        groups = [[0]] + [list(range(s0, min(S, s0 + self.group)))
+                          for s0 in range(1, S, self.group)]
+        pending = [None] * S
+        for ss in groups:
             st.gaussian_axis_batch([self.src_y[k].view(yshape) for s in ss for k in range(nf)],
                                    [self.zy[s][k].view(yshape) for s in ss for k in range(nf)],
                                    sp, 2, [self.sigmas[s] for s in ss for k in range(nf)])
-        pending = [[comm.all_to_all(self.zy[s][k], self.zz[s][k], async_op=self.overlap)
-                    for k in range(nf)] for s in range(S)]
+            for s in ss:
+                pending[s] = [comm.all_to_all(self.zy[s][k], self.zz[s][k],
+                                              async_op=self.overlap) for k in range(nf)]
         lo = 1 if self.rank > 0 else 0
         hi = 1 if self.rank < self.W - 1 else 0
         first = 0 if lo else 1
