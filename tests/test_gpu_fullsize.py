@@ -120,3 +120,40 @@ def test_unsmoothed_path_crop_matches_oracle(ife, oracle, big, dev):
     d = np.abs(got.astype(np.float64) - ref)
     assert (d[..., 0:4] / lam[..., None]).max() <= 1e-6
     assert (mask[z0:z0 + e, y0:y0 + e, x0:x0 + e] != 0).any()
+
+
+def test_config2_256_cubed_unsmoothed_matches_oracle(ife, oracle, synth):
+    """BASELINE configs[1]: 256^3 float32, single scale, Hessian + eigen features without
+    smoothing (a6), whole volume against the oracle."""
+    shape = (256, 256, 256)
+    img = synth.volume_f32(shape, synth.SEED_CONFIG[2])
+    mask = np.minimum(synth.mask_ellipsoids(shape), 1).astype(np.uint8)
+    with ife.Context(0) as c:
+        got = c.fd_hessian_features(img, mask)
+    ref = oracle.fd_hessian_features(img, mask)
+    lam = np.maximum(np.abs(ref[..., 0]).astype(np.float64), 1e-30)
+    d = np.abs(got.astype(np.float64) - ref)
+    assert (d[..., 0:4] / lam[..., None]).max() <= 1e-6
+    assert (d[..., 5] / lam).max() <= 1e-6
+    assert (got[mask == 0] == 0).all()
+
+
+def test_config5_like_int16_five_scales_matches_oracle(ife, oracle, synth):
+    """BASELINE configs[4] shape of work at a size the oracle handles in seconds: int16
+    CT-like input, label mask clamped to {0,1}, anisotropic spacing, five scales."""
+    shape = (64, 192, 256)
+    spacing = (0.7, 0.7, 1.0)
+    sigmas = [1.0, 2.0, 3.0, 4.0, 6.0]
+    img = synth.volume_i16(shape, synth.SEED_CONFIG[5])
+    mask = np.minimum(synth.mask_ellipsoids(shape), 1).astype(np.uint8)
+    with ife.Context(0) as c:
+        got = c.emphysema_features(img, mask, sigmas, spacing)
+    imgf = img.astype(np.float32)
+    for s, sigma in enumerate(sigmas):
+        ref = oracle.emphysema_features(imgf, mask, sigma, spacing)
+        assert np.array_equal(got[s][..., 0], ref[..., 0])
+        assert np.array_equal(got[s][..., 1], ref[..., 1])
+        lam = np.maximum(np.abs(ref[..., 2]).astype(np.float64), 1e-30)
+        d = np.abs(got[s][..., 2:].astype(np.float64) - ref[..., 2:])
+        assert (d[..., 0:4] / lam[..., None]).max() <= 1e-6
+        assert (d[..., 5] / lam).max() <= 1e-6
