@@ -130,13 +130,13 @@ constexpr int FT_NLD = (FT_NE + FT_THREADS - 1) / FT_THREADS;  // staged element
 //  * a second difference float((a - 2c) + b) takes one fma (2c is exact) and one add.
 // Both forms are bit-identical to the generic inner products, except that the sign of
 // an exact zero is not tracked (+0/-0 compare equal and never reach a non-zero output).
-template <int MODE, bool UNIT, int TRIG, typename VAL, typename TM>
+template <int MODE, bool UNIT, int TRIG, bool PLANAR, typename VAL, typename TM>
 #ifndef IFE_FT_WAVES
 #define IFE_FT_WAVES 1
 #endif
 __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL val, const TM *__restrict__ mask,
                                                               float *__restrict__ out, FeatGeom g,
-                                                              DerivCoef dc, int planar) {
+                                                              DerivCoef dc) {
   __shared__ float tile[4][FT_HY][FT_HX];
   // mask tile of the output plane, staged as dwords (per-lane sub-dword global loads are
   // slow on gfx950); row pitch = 64 mask elements
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
   int64_t pidx = -1;
   auto flush = [&]() {
     if (pidx < 0) return;
-    if (planar) {
+    if constexpr (PLANAR) {
 #pragma unroll
       for (int k = 0; k < NOUT; ++k) out[(int64_t)k * g.nvox + pidx] = po[k];
     } else if constexpr (NOUT == 8) {
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
       keep = reinterpret_cast<const TM *>(mtile[z & 1])[ty * FT_TX + tx] != (TM)0;
     else if (mask != nullptr)
       keep = mask[idx] != (TM)0;
-    float o[NOUT];
+    float (&o)[NOUT] = po;  // results are built in the carried registers
 #pragma unroll
     for (int k = 0; k < NOUT; ++k) o[k] = 0.0f;
     // A wave whose 64 voxels are all outside the mask skips the arithmetic (scalar branch);
@@ -342,8 +342,6 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
 #pragma unroll
       for (int k = 0; k < NOUT; ++k) o[k] = 0.0f;
     }
-#pragma unroll
-    for (int k = 0; k < NOUT; ++k) po[k] = o[k];
     pidx = idx;
   }
   flush();

@@ -405,9 +405,14 @@ int launch_features(ife_ctx *ctx, VAL val, const TM *mask, float *out,
   const bool unit = v->sx == 1.0 && v->sy == 1.0 && v->sz == 1.0;
   const int planar = layout == IFE_PLANAR ? 1 : 0;
   constexpr bool has_eig = MODE == FEAT_FEATURES8 || MODE == FEAT_EIG6;
-#define IFE_LAUNCH_FEAT(UNIT_, TRIG_)                                                        \
-  hipLaunchKernelGGL((features_kernel<MODE, UNIT_, TRIG_, VAL, TM>), grid, dim3(FT_THREADS), \
-                     0, ctx->stream, val, mask, out, g, dc, planar)
+#define IFE_LAUNCH_FEAT2(UNIT_, TRIG_, PL_)                                                    \
+  hipLaunchKernelGGL((features_kernel<MODE, UNIT_, TRIG_, PL_, VAL, TM>), grid,                 \
+                     dim3(FT_THREADS), 0, ctx->stream, val, mask, out, g, dc)
+#define IFE_LAUNCH_FEAT(UNIT_, TRIG_)            \
+  do {                                           \
+    if (planar) IFE_LAUNCH_FEAT2(UNIT_, TRIG_, true); \
+    else IFE_LAUNCH_FEAT2(UNIT_, TRIG_, false);  \
+  } while (0)
   if (has_eig && ctx->trig_mode == 1) {
     if constexpr (has_eig) {
       if (unit) IFE_LAUNCH_FEAT(true, 1);
@@ -417,6 +422,7 @@ int launch_features(ife_ctx *ctx, VAL val, const TM *mask, float *out,
     if (unit) IFE_LAUNCH_FEAT(true, 0);
     else IFE_LAUNCH_FEAT(false, 0);
   }
+#undef IFE_LAUNCH_FEAT2
 #undef IFE_LAUNCH_FEAT
   IFE_HIP(ctx, hipGetLastError());
   return IFE_OK;
