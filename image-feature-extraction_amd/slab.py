@@ -7,8 +7,8 @@ slab of every output, so the concatenation of the ranks' outputs in rank order I
 reference's voxel order.
 
 Per step (all scales):
-  prepare          Z-slab   tc = image*mask, cf = float(mask)              (local)
-  exchange #0      all-to-all: Z-slabs -> Y-slabs of tc and cf             (once per step)
+  exchange #0      all-to-all: Z-slabs -> Y-slabs of the raw image and mask (once per step)
+  prepare          Y-slab   tc = image*mask, cf = float(mask)              (local)
   per scale:
     Z pass         Y-slab   every Z line is whole inside a Y-slab          (local)
     exchange #1    all-to-all: Y-slabs -> Z-slabs of the Z-pass output     (per field)
@@ -137,7 +137,7 @@ class SlabEngine:
         self.group = 4 if nf == 2 else 8              # scales per line-kernel launch (<= 8 jobs)
         if nyl % 64 and world > 1:
             raise ValueError("ny/world = %d must be a multiple of 64 (wave-aligned Y chunks)" % nyl)
-        self.src_z = [f(W, nzl, nyl, nx) for _ in range(nf)]      # tc, cf in send order
+        self.raw = None                                           # raw image / mask exchange buffers
         self.src_y = [f(W, nzl, nyl, nx) for _ in range(nf)]      # tc, cf (Y-slab == [nz][nyl][nx])
         # per scale: Z-pass output (Y-slab) and its Y-chunked Z-slab image after exchange #1
         self.zy = [[f(W, nzl, nyl, nx) for _ in range(nf)] for _ in range(S)]
@@ -153,11 +153,24 @@ class SlabEngine:
         yshape = (self.nz, self.nyl, self.nx)
         sp = self.spacing
         S = len(self.sigmas)
-        # Cast + Multiply, written straight in send order; exchange #0
-        st.prepare(img_slab, mask_slab if self.has_mask else None, self.src_z[0],
-                   self.src_z[1] if self.has_mask else None, self.W)
-        for k in range(nf):
-            comm.all_to_all(self.src_z[k], self.src_y[k])
+        # exchange #0 moves the RAW slab (image 4 or 2 B + mask 1 or 2 B per voxel, not the
+        # 8 B of two float fields) re-cut along Y; Cast + Multiply then run on the Y-slab
+        if self.raw is None:
+            import torch
+            mk = lambda t: (torch.empty((self.W, self.nzl, self.nyl, self.nx), dtype=t.dtype,
+                                        device=t.device),
+                            torch.empty((self.W, self.nzl, self.nyl, self.nx), dtype=t.dtype,
+                                        device=t.device))
+            self.raw = [mk(img_slab), mk(mask_slab) if self.has_mask else None]
+        for t, bufs in ((img_slab, self.raw[0]), (mask_slab if self.has_mask else None, self.raw[1])):
+            if t is None:
+                continue
+            send, recv = bufs
+            send.copy_(t.view(self.nzl, self.W, self.nyl, self.nx).permute(1, 0, 2, 3))
+            comm.all_to_all(send, recv)
+        st.prepare(self.raw[0][1].view(yshape),
+                   self.raw[1][1].view(yshape) if self.has_mask else None,
+                   self.src_y[0].view(yshape), self.src_y[1].view(yshape) if self.has_mask else None, 1)
         # Z passes and exchanges #1.  Scale 0 goes alone so that its exchange is on the wire
         # while the remaining scales run their Z pass in ONE launch (a slab has few lines per
         # field: one job per launch would leave most of the device idle); the exchanges of

@@ -45,10 +45,10 @@ class OracleStages:
 
     def prepare(self, img, mask, tc, cf, y_chunks):
         if mask is None:
-            tc.copy_(self._chunk(img.float(), y_chunks))
+            tc.copy_(self._chunk(img.float(), y_chunks).reshape(tc.shape))
         else:
-            tc.copy_(self._chunk(img.float() * mask.float(), y_chunks))
-            cf.copy_(self._chunk(mask.float(), y_chunks))
+            tc.copy_(self._chunk(img.float() * mask.float(), y_chunks).reshape(tc.shape))
+            cf.copy_(self._chunk(mask.float(), y_chunks).reshape(cf.shape))
 
     def gaussian_axis_batch(self, srcs, dsts, spacing, axis, sigmas, in_y_chunks=1):
         import torch
