@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--i16", action="store_true", help="int16 CT-like input (BASELINE configs[4])")
     ap.add_argument("--trig", type=int, default=0)
     ap.add_argument("--iir-block", type=int, default=None)
+    ap.add_argument("--iir-ckpt", type=int, default=None)
     ap.add_argument("--zchunk", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-slab", action="store_true",
@@ -225,6 +226,8 @@ class SingleGpuRunner:
         self.ctx.set_option(pkg.OPT_TRIG_MODE, args.trig)
         if args.iir_block:
             self.ctx.set_option(pkg.OPT_IIR_BLOCK, args.iir_block)
+        if args.iir_ckpt:
+            self.ctx.set_option(pkg.OPT_IIR_CKPT, args.iir_ckpt)
         if args.zchunk:
             self.ctx.set_option(pkg.OPT_ZCHUNK, args.zchunk)
         self.ctx.reserve(shape)

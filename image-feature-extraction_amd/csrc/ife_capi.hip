@@ -60,6 +60,7 @@ struct ife_ctx {
   int profile = 0;
   int zchunk = 64;
   int iir_block = 16;
+  int iir_ckpt = 2;  // register blocks per checkpoint of the strided line kernel: 1 or 2
   // per scale slot: numerator ping/pong, denominator ping/pong (up to three scales run
   // through the line kernels together)
   DevBuf fld[IFE_MAX_SLOTS][4];
@@ -247,7 +248,8 @@ IirGeom geom_for_axis(const ife_volume_desc *v, int axis) {
   return g;
 }
 
-size_t ck_pairs(int64_t n, int K) { return (size_t)((n + 2 * K - 1) / (2 * K)); }
+// checkpoint slots per line: one per register block covers both granularities
+size_t ck_pairs(int64_t n, int K) { return (size_t)((n + K - 1) / K); }
 
 int ensure_ck(ife_ctx *ctx, const ife_volume_desc *v, int njobs) {
   const int K = ctx->iir_block;
@@ -317,10 +319,17 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
     else
       hipLaunchKernelGGL((iir_contig_kernel<16>), grid, dim3(256), 0, ctx->stream, jobs, g);
   } else {
-    if (ctx->iir_block == 8)
-      hipLaunchKernelGGL((iir_strided_kernel<8>), grid, dim3(256), 0, ctx->stream, jobs, g);
-    else
-      hipLaunchKernelGGL((iir_strided_kernel<16>), grid, dim3(256), 0, ctx->stream, jobs, g);
+    if (ctx->iir_ckpt == 1) {
+      if (ctx->iir_block == 8)
+        hipLaunchKernelGGL((iir_strided1_kernel<8>), grid, dim3(256), 0, ctx->stream, jobs, g);
+      else
+        hipLaunchKernelGGL((iir_strided1_kernel<16>), grid, dim3(256), 0, ctx->stream, jobs, g);
+    } else {
+      if (ctx->iir_block == 8)
+        hipLaunchKernelGGL((iir_strided_kernel<8>), grid, dim3(256), 0, ctx->stream, jobs, g);
+      else
+        hipLaunchKernelGGL((iir_strided_kernel<16>), grid, dim3(256), 0, ctx->stream, jobs, g);
+    }
   }
   IFE_HIP(ctx, hipGetLastError());
   return IFE_OK;
@@ -582,6 +591,10 @@ int ife_ctx_set_option(ife_ctx *ctx, int option, int value) {
     case IFE_OPT_ZCHUNK:
       if (value < 1) return fail(ctx, IFE_E_ARG, "zchunk must be >= 1");
       ctx->zchunk = value;
+      return IFE_OK;
+    case IFE_OPT_IIR_CKPT:
+      if (value != 1 && value != 2) return fail(ctx, IFE_E_ARG, "iir checkpoint stride must be 1 or 2");
+      ctx->iir_ckpt = value;
       return IFE_OK;
     case IFE_OPT_IIR_BLOCK:
       if (value != 8 && value != 16) return fail(ctx, IFE_E_ARG, "iir block must be 8 or 16");

@@ -127,6 +127,27 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *ubase) {
   // stride 0, no range limit: offsets are validated on the host (ife_capi.hip)
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ubase), 0, -1, 0x00020000);
 }
+// Timing-only diagnostics (MI355X guide, "price ONE buffer's traffic"): a resource with zero
+// records drops every access through it while the instruction stream stays.  Never defined
+// in the product build; results are wrong by construction.
+__device__ __forceinline__ rsrc_t make_rsrc_null(const void *ubase) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ubase), 0, 0, 0x00020000);
+}
+#if defined(IFE_DIAG_NO_OUT)
+#define IFE_OUT_RSRC make_rsrc_null
+#else
+#define IFE_OUT_RSRC make_rsrc
+#endif
+#if defined(IFE_DIAG_NO_CK)
+#define IFE_CK_RSRC make_rsrc_null
+#else
+#define IFE_CK_RSRC make_rsrc
+#endif
+#if defined(IFE_DIAG_NO_IN)
+#define IFE_IN_RSRC make_rsrc_null
+#else
+#define IFE_IN_RSRC make_rsrc
+#endif
 __device__ __forceinline__ float buf_ld_f32(rsrc_t r, uint32_t voff, uint32_t soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
@@ -179,7 +200,7 @@ struct IirJobs {
 struct SrcF32 {
   const float *p;
   struct At { rsrc_t a; };
-  __device__ __forceinline__ At at(int64_t u) const { return At{make_rsrc(p + u)}; }
+  __device__ __forceinline__ At at(int64_t u) const { return At{IFE_IN_RSRC(p + u)}; }
   __device__ __forceinline__ float ld(const At &b, uint32_t v, uint32_t s) const {
     return buf_ld_f32(b.a, v * 4u, s * 4u);
   }
@@ -195,7 +216,7 @@ struct Checkpoint {
 // the sweep loads anyway).  That is 32 B per line per 32 samples each way.
 __device__ __forceinline__ void ck_store(const Checkpoint &ck, int64_t pair, int64_t nl,
                                          int64_t Lw, uint32_t lane, const CausalState &s) {
-  const rsrc_t ry = make_rsrc(ck.y + (pair * 4) * nl + Lw);
+  const rsrc_t ry = IFE_CK_RSRC(ck.y + (pair * 4) * nl + Lw);
   const uint32_t sy = (uint32_t)nl * 8u;
   buf_st_f64(ry, lane * 8u, 0u, s.y1);
   buf_st_f64(ry, lane * 8u, sy, s.y2);
@@ -204,7 +225,7 @@ __device__ __forceinline__ void ck_store(const Checkpoint &ck, int64_t pair, int
 }
 __device__ __forceinline__ void ck_load(const Checkpoint &ck, int64_t pair, int64_t nl,
                                         int64_t Lw, uint32_t lane, CausalState &s) {
-  const rsrc_t ry = make_rsrc(ck.y + (pair * 4) * nl + Lw);
+  const rsrc_t ry = IFE_CK_RSRC(ck.y + (pair * 4) * nl + Lw);
   const uint32_t sy = (uint32_t)nl * 8u;
   s.y1 = buf_ld_f64(ry, lane * 8u, 0u);
   s.y2 = buf_ld_f64(ry, lane * 8u, sy);
@@ -407,7 +428,7 @@ __global__ __launch_bounds__(256) void iir_strided_kernel(IirJobs jobs, IirGeom 
       }
       const bool head = p == 0;                 // border form at the line start
       const bool tail = i1 + K + 4 > n;         // second block touches the last 4 samples
-      const rsrc_t ro = make_rsrc(out + wbase + i0 * st);
+      const rsrc_t ro = IFE_OUT_RSRC(out + wbase + i0 * st);
       double cz[K];
       if (i1 < n) {  // second block of the pair exists: run through the first to reach it
         CausalState s = s0;
@@ -434,6 +455,133 @@ __global__ __launch_bounds__(256) void iir_strided_kernel(IirJobs jobs, IirGeom 
       }
 #pragma unroll
       for (int j = 0; j < K; ++j) { xa[j] = na[j]; xb[j] = nb2[j]; }
+      h1 = nh1; h2 = nh2; h3 = nh3;
+      sc.y1 = sn.y1; sc.y2 = sn.y2; sc.y3 = sn.y3; sc.y4 = sn.y4;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Strided variant with a checkpoint in front of EVERY register block: 16 B/voxel more
+// checkpoint traffic than the pair form, but no block is recomputed twice (the pair form
+// spends 8 of its 58 double operations per sample on that, and the kernel is bound by
+// double-precision issue, not by HBM: with all memory traffic removed it still takes 75 %
+// of its time).
+// ---------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void iir_strided1_kernel(IirJobs jobs, IirGeom g) {
+  const IirJob &J = jobs.j[blockIdx.y];
+  const SrcF32 src{J.in};
+  float *__restrict__ out = J.out;
+  const IirCoef c = J.c;
+  const Checkpoint ck{J.ck_y, J.ck_x};
+  const uint32_t lane = threadIdx.x & 63u;
+  const int64_t Lw =
+      uniform64((int64_t)blockIdx.x * blockDim.x + (int64_t)(threadIdx.x & ~63u));
+  if (Lw >= g.nlines) return;  // wave-uniform
+  const int64_t n = g.n, st = g.sstride, nl = g.nlines;
+  int64_t L = Lw + lane;
+  const bool live = L < nl;
+  if (!live) L = nl - 1;
+  const int64_t base = (L % g.inner) + (L / g.inner) * g.outer;
+  const int64_t wbase = uniform64(base);
+  const uint32_t voff = (uint32_t)(base - wbase);
+  const uint32_t sst = (uint32_t)st;
+  const int64_t nb = (n + K - 1) / K;
+
+  // ---------------- forward sweep: checkpoint b+1 after block b, b <= nb-2 ----------------
+  {
+    float xb[K], xn[K];
+    CausalState s;
+    if (nb > 1) {
+      const auto B = src.at(wbase);
+#pragma unroll
+      for (int j = 0; j < K; ++j) xb[j] = src.ld(B, voff, (uint32_t)j * sst);
+    }
+    for (int64_t b = 0; b + 1 < nb; ++b) {
+      const int64_t i0 = b * K;
+      if (b + 2 < nb) {
+        const auto B = src.at(wbase + (i0 + K) * st);
+#pragma unroll
+        for (int j = 0; j < K; ++j) xn[j] = src.ld(B, voff, (uint32_t)j * sst);
+      }
+      if (b > 0) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) causal_step(s, (double)xb[j], c);
+      } else {
+        const double x0 = (double)xb[0];
+        s.x1 = s.x2 = s.x3 = x0;
+        s.y1 = s.y2 = s.y3 = s.y4 = x0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) causal_step_edge(s, (double)xb[j], c, j);
+      }
+      if (live) ck_store(ck, b + 1, nl, Lw, lane, s);
+#pragma unroll
+      for (int j = 0; j < K; ++j) xb[j] = xn[j];
+    }
+  }
+
+  // ---------------- backward sweep, one block per iteration ----------------
+  {
+    float xa[K], na[K];
+    float h1 = 0.f, h2 = 0.f, h3 = 0.f, nh1 = 0.f, nh2 = 0.f, nh3 = 0.f;
+    AntiState a;
+    CausalState sc, sn;
+    sc.y1 = sc.y2 = sc.y3 = sc.y4 = 0.0;
+    sn = sc;
+    auto load_hist = [&](int64_t b, float &q1, float &q2, float &q3) {
+      const auto B = src.at(wbase + (b * K - 3) * st);  // b >= 1
+      q3 = src.ld(B, voff, 0u);
+      q2 = src.ld(B, voff, sst);
+      q1 = src.ld(B, voff, 2u * sst);
+    };
+    {
+      const int64_t i0 = (nb - 1) * K;
+      const auto B = src.at(wbase + i0 * st);
+      const uint32_t lastj = (uint32_t)(n - 1 - i0);
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+        xa[j] = src.ld(B, voff, ((uint32_t)j < lastj ? (uint32_t)j : lastj) * sst);
+      if (nb > 1) {
+        load_hist(nb - 1, h1, h2, h3);
+        ck_load(ck, nb - 1, nl, Lw, live ? lane : 0u, sc);
+      }
+      const double xN = (double)xa[K - 1];
+      a.x1 = a.x2 = a.x3 = a.x4 = xN;
+      a.y1 = a.y2 = a.y3 = a.y4 = xN;
+    }
+    for (int64_t b = nb - 1; b >= 0; --b) {
+      const int64_t i0 = b * K;
+      if (b > 0) {  // all loads of the iteration come before its stores
+        const auto B = src.at(wbase + (i0 - K) * st);
+#pragma unroll
+        for (int j = 0; j < K; ++j) na[j] = src.ld(B, voff, (uint32_t)j * sst);
+        if (b > 1) {
+          load_hist(b - 1, nh1, nh2, nh3);
+          ck_load(ck, b - 1, nl, Lw, live ? lane : 0u, sn);
+        }
+      }
+      CausalState s;
+      if (b > 0) {
+        s.y1 = sc.y1; s.y2 = sc.y2; s.y3 = sc.y3; s.y4 = sc.y4;
+        s.x1 = (double)h1; s.x2 = (double)h2; s.x3 = (double)h3;
+      } else {
+        const double x0 = (double)xa[0];
+        s.x1 = s.x2 = s.x3 = x0;
+        s.y1 = s.y2 = s.y3 = s.y4 = x0;
+      }
+      const bool edge = (b == 0) || (i0 + K + 4 > n);
+      double cz[K];
+      causal_run<K, true>(s, xa, cz, c, i0, n, edge);
+      anti_run<K>(a, xa, cz, c, i0, n, edge);
+      if (live) {
+        const rsrc_t ro = IFE_OUT_RSRC(out + wbase + i0 * st);
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+          if (!edge || i0 + j < n) buf_st_f32(ro, voff * 4u, (uint32_t)j * sst * 4u, xa[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < K; ++j) xa[j] = na[j];
       h1 = nh1; h2 = nh2; h3 = nh3;
       sc.y1 = sn.y1; sc.y2 = sn.y2; sc.y3 = sn.y3; sc.y4 = sn.y4;
     }

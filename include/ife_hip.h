@@ -68,7 +68,10 @@ typedef enum {
   /* planes per workgroup march of the feature kernel (default 64) */
   IFE_OPT_ZCHUNK = 4,
   /* samples per register block of the recursive-Gaussian kernels: 8 or 16 */
-  IFE_OPT_IIR_BLOCK = 5
+  IFE_OPT_IIR_BLOCK = 5,
+  /* register blocks per checkpoint of the strided (z, y) line kernel: 2 (default, measured
+   * faster) or 1 */
+  IFE_OPT_IIR_CKPT = 6
 } ife_option;
 
 typedef struct {
