@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--trig", type=int, default=0)
     ap.add_argument("--iir-block", type=int, default=None)
     ap.add_argument("--iir-ckpt", type=int, default=None)
+    ap.add_argument("--iir-fma", action="store_true", help="opt-in fused recurrences (not bit-exact)")
     ap.add_argument("--zchunk", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-slab", action="store_true",
@@ -228,6 +229,8 @@ class SingleGpuRunner:
             self.ctx.set_option(pkg.OPT_IIR_BLOCK, args.iir_block)
         if args.iir_ckpt:
             self.ctx.set_option(pkg.OPT_IIR_CKPT, args.iir_ckpt)
+        if args.iir_fma:
+            self.ctx.set_option(pkg.OPT_IIR_FMA, 1)
         if args.zchunk:
             self.ctx.set_option(pkg.OPT_ZCHUNK, args.zchunk)
         self.ctx.reserve(shape)

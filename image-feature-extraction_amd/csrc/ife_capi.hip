@@ -1,7 +1,7 @@
 // ife_capi.hip -- C-ABI (include/ife_hip.h) over the HIP kernels.  gfx950 only.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
-// (-ffp-contract=off is part of the numerical contract, see iir_kernels.hpp).
+// (-ffp-contract=off is part of the numerical contract, see iir_kernels.inc).
 #include "../../include/ife_hip.h"
 
 #include <hip/hip_runtime.h>
@@ -16,7 +16,17 @@
 #include <vector>
 
 #include "feature_kernels.hpp"
-#include "iir_kernels.hpp"
+#include "iir_types.hpp"
+#define IFE_IIR_NS iir_exact
+#define IFE_IIR_FMA 0
+#include "iir_kernels.inc"
+#undef IFE_IIR_NS
+#undef IFE_IIR_FMA
+#define IFE_IIR_NS iir_fma
+#define IFE_IIR_FMA 1
+#include "iir_kernels.inc"
+#undef IFE_IIR_NS
+#undef IFE_IIR_FMA
 
 using namespace ife;
 
@@ -60,6 +70,7 @@ struct ife_ctx {
   int profile = 0;
   int zchunk = 64;
   int iir_block = 16;
+  int iir_fma = 0;   // 1: fused multiply-add in the line recurrences (opt-in, not bit-exact)
   int iir_ckpt = 2;  // register blocks per checkpoint of the strided line kernel: 1 or 2
   // per scale slot: numerator ping/pong, denominator ping/pong (up to three scales run
   // through the line kernels together)
@@ -293,7 +304,7 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
     g.in_group = v->ny / in_y_chunks;
     g.in_nz = v->nz;
   }
-  // 32-bit offsets of the buffer accesses (iir_kernels.hpp "addressing")
+  // 32-bit offsets of the buffer accesses (iir_kernels.inc "addressing")
   if ((int64_t)2 * ctx->iir_block * g.sstride * 4 >= (int64_t)1 << 31 ||
       g.outer * 4 >= (int64_t)1 << 32 || g.nlines * 8 * 3 >= (int64_t)1 << 32)
     return fail(ctx, IFE_E_SIZE, "volume too large for the 32-bit offsets of the line kernels");
@@ -313,24 +324,28 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
   }
   const dim3 grid((unsigned)((g.nlines + 255) / 256), (unsigned)njobs, 1);
   ProfScope ps(ctx, axis == 2 ? KK_IIR_Z : axis == 1 ? KK_IIR_Y : KK_IIR_X);
-  if (axis == 0) {
-    if (ctx->iir_block == 8)
-      hipLaunchKernelGGL((iir_contig_kernel<8>), grid, dim3(256), 0, ctx->stream, jobs, g);
-    else
-      hipLaunchKernelGGL((iir_contig_kernel<16>), grid, dim3(256), 0, ctx->stream, jobs, g);
-  } else {
-    if (ctx->iir_ckpt == 1) {
-      if (ctx->iir_block == 8)
-        hipLaunchKernelGGL((iir_strided1_kernel<8>), grid, dim3(256), 0, ctx->stream, jobs, g);
-      else
-        hipLaunchKernelGGL((iir_strided1_kernel<16>), grid, dim3(256), 0, ctx->stream, jobs, g);
-    } else {
-      if (ctx->iir_block == 8)
-        hipLaunchKernelGGL((iir_strided_kernel<8>), grid, dim3(256), 0, ctx->stream, jobs, g);
-      else
-        hipLaunchKernelGGL((iir_strided_kernel<16>), grid, dim3(256), 0, ctx->stream, jobs, g);
-    }
-  }
+#define IFE_LAUNCH_IIR(NS)                                                                      \
+  do {                                                                                          \
+    if (axis == 0) {                                                                            \
+      if (ctx->iir_block == 8)                                                                  \
+        hipLaunchKernelGGL((NS::iir_contig_kernel<8>), grid, dim3(256), 0, ctx->stream, jobs, g); \
+      else                                                                                      \
+        hipLaunchKernelGGL((NS::iir_contig_kernel<16>), grid, dim3(256), 0, ctx->stream, jobs, g); \
+    } else if (ctx->iir_ckpt == 1) {                                                            \
+      if (ctx->iir_block == 8)                                                                  \
+        hipLaunchKernelGGL((NS::iir_strided1_kernel<8>), grid, dim3(256), 0, ctx->stream, jobs, g); \
+      else                                                                                      \
+        hipLaunchKernelGGL((NS::iir_strided1_kernel<16>), grid, dim3(256), 0, ctx->stream, jobs, g); \
+    } else {                                                                                    \
+      if (ctx->iir_block == 8)                                                                  \
+        hipLaunchKernelGGL((NS::iir_strided_kernel<8>), grid, dim3(256), 0, ctx->stream, jobs, g); \
+      else                                                                                      \
+        hipLaunchKernelGGL((NS::iir_strided_kernel<16>), grid, dim3(256), 0, ctx->stream, jobs, g); \
+    }                                                                                           \
+  } while (0)
+  if (ctx->iir_fma) IFE_LAUNCH_IIR(iir_fma);
+  else IFE_LAUNCH_IIR(iir_exact);
+#undef IFE_LAUNCH_IIR
   IFE_HIP(ctx, hipGetLastError());
   return IFE_OK;
 }
@@ -591,6 +606,9 @@ int ife_ctx_set_option(ife_ctx *ctx, int option, int value) {
     case IFE_OPT_ZCHUNK:
       if (value < 1) return fail(ctx, IFE_E_ARG, "zchunk must be >= 1");
       ctx->zchunk = value;
+      return IFE_OK;
+    case IFE_OPT_IIR_FMA:
+      ctx->iir_fma = value ? 1 : 0;
       return IFE_OK;
     case IFE_OPT_IIR_CKPT:
       if (value != 1 && value != 2) return fail(ctx, IFE_E_ARG, "iir checkpoint stride must be 1 or 2");

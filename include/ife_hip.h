@@ -71,7 +71,11 @@ typedef enum {
   IFE_OPT_IIR_BLOCK = 5,
   /* register blocks per checkpoint of the strided (z, y) line kernel: 2 (default, measured
    * faster) or 1 */
-  IFE_OPT_IIR_CKPT = 6
+  IFE_OPT_IIR_CKPT = 6,
+  /* 1: fuse each multiply-add of the recursive Gaussian (half the double operations).  Not
+   * the reference's arithmetic: outputs differ by one float ulp at about one voxel in 10^8,
+   * which the second differences can amplify past the 1e-5 bar there.  Default 0. */
+  IFE_OPT_IIR_FMA = 7
 } ife_option;
 
 typedef struct {

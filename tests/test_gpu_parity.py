@@ -321,3 +321,40 @@ def test_golden_fd_snapshot_on_device(ctx):
 def test_golden_eigen_fixture_on_device(ctx):
     z = np.load(os.path.join(HERE, "golden", "eigen_f32.npz"))
     assert eig_rel_err(ctx.eigenvalues(z["A"]), z["ev_cmath"]) <= REL_TOL
+
+
+# ---------------------------------------------------------------------------------
+# opt-in variants: must stay inside the north_star bar, are NOT expected to be bit exact
+# ---------------------------------------------------------------------------------
+def test_fused_recurrence_option_stays_inside_the_bar(ctx, ife, oracle, synth):
+    """IFE_OPT_IIR_FMA fuses each multiply-add of the recursive Gaussian.  The smoothed
+    value may then differ from the reference arithmetic by one float ulp at rare voxels."""
+    shape = (48, 52, 56)
+    img = synth.volume_f32(shape, 31)
+    mask = np.ones(shape, np.uint8)
+    ctx.set_option(ife.OPT_IIR_FMA, 1)
+    try:
+        got = ctx.emphysema_features(img, mask, [1.0, 4.0])
+    finally:
+        ctx.set_option(ife.OPT_IIR_FMA, 0)
+    for s, sigma in enumerate((1.0, 4.0)):
+        ref = oracle.emphysema_features(img, mask, sigma)
+        same = float((got[s][..., 0] == ref[..., 0]).mean())
+        ulp = np.spacing(np.abs(ref[..., 0]))
+        assert same > 0.9999 and (np.abs(got[s][..., 0] - ref[..., 0]) <= ulp).all()
+        lam = np.maximum(np.abs(ref[..., 2]).astype(np.float64), 1e-30)
+        err = np.abs(got[s][..., 2:5].astype(np.float64) - ref[..., 2:5]) / lam[..., None]
+        assert np.quantile(err, 0.9999) <= 1e-5
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_checkpoint_stride_is_invisible(ctx, ife, oracle, synth, stride):
+    shape = (70, 41, 45)
+    img = synth.volume_f32(shape, 98)
+    cert = np.ones(shape, np.float32)
+    ctx.set_option(ife.OPT_IIR_CKPT, stride)
+    try:
+        got = ctx.normalized_gaussian_convolution(img, cert, 2.0)
+    finally:
+        ctx.set_option(ife.OPT_IIR_CKPT, 2)
+    np.testing.assert_array_equal(got, oracle.normalized_gaussian_convolution(img, cert, 2.0))
