@@ -176,6 +176,7 @@ def main():
         traffic = json.load(open(tpath)).get("traffic_bytes_per_step")
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_step": int(alg_bytes_step_rank),
                 "traffic_source": "profiles/r01_traffic.json (rocprofv3 PMC, bytes per step)"
                 if traffic else None,
                 "scope": "all kernels of one step (sum of hipEvent durations %.3f ms); "
