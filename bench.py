@@ -74,10 +74,35 @@ def cpu_baseline(synth, seed, sigmas, edge):
     for s in sigmas:
         pyoracle.emphysema_features(img, mask, float(s))
     dt = time.perf_counter() - t0
+    # one-thread figure on a 128^3 corner (SURVEY.md 8d asks for both)
+    pyoracle.set_threads(1)
+    e1 = min(edge, 128)
+    img1, mask1 = img[:e1, :e1, :e1].copy(), mask[:e1, :e1, :e1].copy()
+    t1 = time.perf_counter()
+    for s in sigmas:
+        pyoracle.emphysema_features(img1, mask1, float(s))
+    dt1 = time.perf_counter() - t1
+    pyoracle.set_threads(threads)
     return {"value": round(edge ** 3 * len(sigmas) / dt / 1e6, 3), "unit": "Mvoxels/s",
             "cores": threads, "kind": "port",
+            "one_thread_value": round(e1 ** 3 * len(sigmas) / dt1 / 1e6, 3),
             "sample": "%d^3 corner of the same synthetic volume, sigmas %s, all-ones mask, "
                       "%.1f s of CPU work" % (edge, list(sigmas), dt)}
+
+
+def measured_copy_gbs(torch, dev, nbytes=1 << 30, reps=5):
+    """Device-to-device copy rate (bytes read + bytes written per second): the achievable
+    HBM ceiling on this box, printed beside the 8 TB/s peak."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).fill_(1.0)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def main():
@@ -134,6 +159,7 @@ def main():
     dt = time.perf_counter() - t0
     ktimes = runner.ctx.kernel_times()
     runner.ctx.set_option(pkg.OPT_PROFILE, 0)
+    copy_gbs = measured_copy_gbs(torch, dev) if rank == 0 else None
 
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -177,6 +203,7 @@ def main():
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_step": int(alg_bytes_step_rank),
+                "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
                 "traffic_source": "profiles/r01_traffic.json (rocprofv3 PMC, bytes per step)"
                 if traffic else None,
                 "scope": "all kernels of one step (sum of hipEvent durations %.3f ms); "
@@ -197,6 +224,7 @@ def main():
                                          + ("" if list(args.spacing) == [1.0, 1.0, 1.0]
                                             else ", spacing %s" % list(args.spacing))),
                    "trig_mode": args.trig},
+        "volume_level_Mvoxels_per_s": round(nvox / t_step / 1e6, 1),
         "roofline": roofline,
     }
     if rank == 0:

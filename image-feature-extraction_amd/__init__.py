@@ -40,6 +40,10 @@ EXPORTS = (
     "ife_get_kernel_times", "ife_reset_kernel_times",
     "ife_stage_prepare", "ife_stage_recursive_gaussian", "ife_stage_recursive_gaussian_batch",
     "ife_stage_features",
+    "ife_sort_f32", "ife_equalized_edges_f32", "ife_dense_histogram_f32",
+    "ife_samples_create", "ife_samples_destroy", "ife_samples_count", "ife_samples_clear",
+    "ife_samples_add_features", "ife_samples_add_image", "ife_samples_sort",
+    "ife_samples_equalized_edges", "ife_samples_read_column",
 )
 
 
@@ -100,6 +104,21 @@ def load_library():
     lib.ife_stage_features.argtypes = [vp, vp, vp, vp, i32, vd, i32, i32, vp, i32]
     lib.ife_get_kernel_times.argtypes = [vp, C.POINTER(KernelTime), i32]
     lib.ife_reset_kernel_times.argtypes = [vp]
+    lib.ife_sort_f32.argtypes = [vp, vp, i64, vp, i32]
+    lib.ife_equalized_edges_f32.argtypes = [vp, vp, i64, i32, vp, i32]
+    lib.ife_dense_histogram_f32.argtypes = [vp, vp, i32, vp, i64, vp, i32]
+    lib.ife_samples_create.argtypes = [vp, i32, C.POINTER(vp)]
+    lib.ife_samples_destroy.argtypes = [vp]
+    lib.ife_samples_destroy.restype = None
+    lib.ife_samples_count.argtypes = [vp, i32, C.POINTER(i64)]
+    lib.ife_samples_clear.argtypes = [vp]
+    lib.ife_samples_add_features.argtypes = [vp, vp, i32, vp, i32, i32, vp, i32, i64, vp, i32,
+                                             vp, i64, i32]
+    lib.ife_samples_add_image.argtypes = [vp, vp, vp, i32, vp, i32, vd, C.POINTER(C.c_float),
+                                          i32, vp, i32, vp, i64, i32]
+    lib.ife_samples_sort.argtypes = [vp, vp]
+    lib.ife_samples_equalized_edges.argtypes = [vp, vp, i32, vp]
+    lib.ife_samples_read_column.argtypes = [vp, vp, i32, vp, i64]
     _lib = lib
     return lib
 
@@ -321,3 +340,130 @@ class Context:
             self._h, C.c_void_p(num_ptr), C.c_void_p(den_ptr or 0), C.c_void_p(mask_ptr or 0),
             mask_dtype, C.byref(d), int(bool(halo_lo)), int(bool(halo_hi)), C.c_void_p(out_ptr),
             layout))
+
+    # ---- rows f1 / f2: sample columns, histogram edges, dense histograms --------------
+    def sort_f32(self, values):
+        v = np.ascontiguousarray(values, np.float32).ravel()
+        out = np.empty_like(v)
+        self._chk(self._lib.ife_sort_f32(self._h, v.ctypes.data, v.size, out.ctypes.data, MEM_HOST))
+        return out
+
+    def sort_f32_device(self, in_ptr, n, out_ptr):
+        self._chk(self._lib.ife_sort_f32(self._h, C.c_void_p(in_ptr), int(n), C.c_void_p(out_ptr),
+                                         MEM_DEVICE))
+
+    def equalized_edges(self, sorted_values, nbins):
+        """determineEdgesForEqualizedHistogram on an ascending float32 array."""
+        v = np.ascontiguousarray(sorted_values, np.float32).ravel()
+        out = np.empty(max(int(nbins) - 1, 0), np.float32)
+        self._chk(self._lib.ife_equalized_edges_f32(self._h, v.ctypes.data, v.size, int(nbins),
+                                                    out.ctypes.data, MEM_HOST))
+        return out
+
+    def dense_histogram(self, edges, values):
+        e = np.ascontiguousarray(edges, np.float32).ravel()
+        v = np.ascontiguousarray(values, np.float32).ravel()
+        counts = np.empty(e.size + 1, np.uint32)
+        self._chk(self._lib.ife_dense_histogram_f32(self._h, e.ctypes.data, e.size, v.ctypes.data,
+                                                    v.size, counts.ctypes.data, MEM_HOST))
+        return counts
+
+    def samples(self, n_columns):
+        return Samples(self, n_columns)
+
+
+class Samples:
+    """``ife_samples``: one growing device-resident column per (scale, feature), the
+    `samples` vector of tools/DetermineHistogramBinEdges_MultiScaleEigenvalueFeatures.cxx."""
+
+    def __init__(self, ctx, n_columns):
+        self._ctx, self._lib = ctx, ctx._lib
+        self.n_columns = int(n_columns)
+        h = C.c_void_p()
+        ctx._chk(self._lib.ife_samples_create(ctx._h, self.n_columns, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self._ctx, "_h", None):
+            self._lib.ife_samples_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def count(self, column=0):
+        n = C.c_int64()
+        self._ctx._chk(self._lib.ife_samples_count(self._h, int(column), C.byref(n)))
+        return n.value
+
+    def clear(self):
+        self._ctx._chk(self._lib.ife_samples_clear(self._h))
+
+    @staticmethod
+    def _fg(foreground):
+        fg = np.ascontiguousarray(foreground, np.uint32).ravel()
+        return fg, (fg.ctypes.data if fg.size else None)
+
+    def add_features(self, first_column, features, mask=None, foreground=(1,), indices=None,
+                     layout=INTERLEAVED):
+        """features: (nz, ny, nx, ncomp) interleaved or (ncomp, nz, ny, nx) planar, host."""
+        f = np.ascontiguousarray(features, np.float32)
+        ncomp = f.shape[-1] if layout == INTERLEAVED else f.shape[0]
+        nvox = f.size // ncomp
+        fg, fgp = self._fg(foreground)
+        mptr, mdt, iptr, ni = None, U8, None, 0
+        if indices is not None:
+            indices = np.ascontiguousarray(indices, np.int64).ravel()
+            iptr, ni = indices.ctypes.data, indices.size
+        else:
+            mask = np.ascontiguousarray(mask)
+            mptr, mdt = mask.ctypes.data, _MSK_DT[mask.dtype]
+        self._ctx._chk(self._lib.ife_samples_add_features(
+            self._ctx._h, self._h, int(first_column), f.ctypes.data, layout, ncomp, mptr, mdt, nvox,
+            fgp, fg.size, iptr, ni, MEM_HOST))
+
+    def add_image(self, image, mask, sigmas, foreground=(1,), indices=None,
+                  spacing=(1.0, 1.0, 1.0)):
+        """One image of the tool's loop: features at every scale stay on the device."""
+        image = np.ascontiguousarray(image)
+        if image.dtype not in _IMG_DT:
+            image = image.astype(np.float32)
+        mask = np.ascontiguousarray(mask)
+        d = _desc(image.shape, spacing)
+        sig = (C.c_float * len(sigmas))(*[float(s) for s in sigmas])
+        fg, fgp = self._fg(foreground)
+        iptr, ni = None, 0
+        if indices is not None:
+            indices = np.ascontiguousarray(indices, np.int64).reshape(len(sigmas), -1)
+            iptr, ni = indices.ctypes.data, indices.shape[1]
+        self._ctx._chk(self._lib.ife_samples_add_image(
+            self._ctx._h, self._h, image.ctypes.data, _IMG_DT[image.dtype], mask.ctypes.data,
+            _MSK_DT[mask.dtype], C.byref(d), sig, len(sigmas), fgp, fg.size, iptr, ni, MEM_HOST))
+
+    def add_image_device(self, image_ptr, image_dtype, mask_ptr, mask_dtype, shape_zyx, sigmas,
+                         foreground=(1,), spacing=(1.0, 1.0, 1.0)):
+        d = _desc(shape_zyx, spacing)
+        sig = (C.c_float * len(sigmas))(*[float(s) for s in sigmas])
+        fg, fgp = self._fg(foreground)
+        self._ctx._chk(self._lib.ife_samples_add_image(
+            self._ctx._h, self._h, C.c_void_p(image_ptr), image_dtype, C.c_void_p(mask_ptr),
+            mask_dtype, C.byref(d), sig, len(sigmas), fgp, fg.size, None, 0, MEM_DEVICE))
+
+    def sort(self):
+        self._ctx._chk(self._lib.ife_samples_sort(self._ctx._h, self._h))
+
+    def equalized_edges(self, nbins):
+        """(n_columns, nbins-1) float32: one row per (scale, feature) as the tool writes them."""
+        out = np.empty((self.n_columns, max(int(nbins) - 1, 0)), np.float32)
+        self._ctx._chk(self._lib.ife_samples_equalized_edges(self._ctx._h, self._h, int(nbins),
+                                                             out.ctypes.data))
+        return out
+
+    def column(self, column):
+        out = np.empty(self.count(column), np.float32)
+        self._ctx._chk(self._lib.ife_samples_read_column(self._ctx._h, self._h, int(column),
+                                                         out.ctypes.data, out.size))
+        return out

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -17,6 +18,7 @@
 
 #include "feature_kernels.hpp"
 #include "iir_types.hpp"
+#include "stats_kernels.hpp"
 #define IFE_IIR_NS iir_exact
 #define IFE_IIR_FMA 0
 #include "iir_kernels.inc"
@@ -41,10 +43,17 @@ enum KernelKind {
   KK_DIVIDE,
   KK_MASK,
   KK_PREP,
+  KK_SORT_HIST,
+  KK_SORT_SCAN,
+  KK_SORT_SCATTER,
+  KK_GATHER,
+  KK_EDGES,
+  KK_HIST,
   KK_COUNT
 };
-const char *kKindNames[KK_COUNT] = {"iir_z", "iir_x", "iir_y", "features",
-                                    "eig_batch", "divide", "mask_f64", "prep"};
+const char *kKindNames[KK_COUNT] = {"iir_z", "iir_x", "iir_y", "features", "eig_batch",
+                                    "divide", "mask_f64", "prep", "sort_hist", "sort_scan",
+                                    "sort_scatter", "gather", "edges", "dense_histogram"};
 
 struct DevBuf {
   void *p = nullptr;
@@ -954,3 +963,5 @@ int ife_reset_kernel_times(ife_ctx *ctx) {
 }
 
 }  // extern "C"
+
+#include "stats_capi.inc"

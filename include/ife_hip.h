@@ -222,6 +222,67 @@ int ife_stage_features(ife_ctx *ctx, const float *num, const float *den, const v
                        int mask_dtype, const ife_volume_desc *slab, int halo_lo, int halo_hi,
                        float *out, int layout);
 
+/* ---- rows f1 / f2: sample columns, equalizing histogram edges, dense histograms ------- *
+ * The immediate consumer of the feature volume.  The samples never
+ * leave HBM; only the nbins-1 edges per column come back.                                 */
+
+/* std::sort of one sample column
+ * (tools/DetermineHistogramBinEdges_MultiScaleEigenvalueFeatures.cxx:284).  Ascending;
+ * -0 sorts before +0 (std::sort leaves their order unspecified).  in == out is allowed. */
+int ife_sort_f32(ife_ctx *ctx, const float *in, int64_t n, float *out, int mem);
+
+/* determineEdgesForEqualizedHistogram(first, last, d_first, nBins),
+ * include/ife/Statistics/DetermineEdgesForEqualizedHistogram.h:21-137.  sorted[0..n) must
+ * be ascending; writes nbins-1 edges.  IFE_E_ARG when n < nbins (std::out_of_range there,
+ * :36-38); IFE_E_STATE when the walk would pass the last sample (an assert there, :74). */
+int ife_equalized_edges_f32(ife_ctx *ctx, const float *sorted, int64_t n, int nbins,
+                            float *edges, int mem);
+
+/* DenseHistogram<float>: insert every value, getCounts
+ * (include/ife/Statistics/DenseHistogram.h:29-64).  Bins (-inf,e0], (e0,e1], ...,
+ * (e_last,inf); counts holds n_edges+1 entries; 1 <= n_edges <= 1024. */
+int ife_dense_histogram_f32(ife_ctx *ctx, const float *edges, int n_edges, const float *values,
+                            int64_t n, uint32_t *counts, int mem);
+
+/* The tool's `samples( scales.size() * numFeatures )` (:165-166): one growing column per
+ * (scale, feature), kept in device memory.  Belongs to the context it was created on. */
+typedef struct ife_samples ife_samples;
+int ife_samples_create(ife_ctx *ctx, int n_columns, ife_samples **out);
+void ife_samples_destroy(ife_samples *s);
+int ife_samples_count(const ife_samples *s, int column, int64_t *n);
+int ife_samples_clear(ife_samples *s);
+
+/* Append the ncomp feature values of the accepted voxels of one feature volume to columns
+ * [first_column, first_column+ncomp).  indices == NULL: every voxel whose mask value
+ * equals one of foreground[0..n_foreground) (the nSamples == 0 branch, :221-236;
+ * 1 <= n_foreground <= 8).  indices != NULL: the listed voxels, x-fastest linear index,
+ * repeats allowed (the sampled branch, :238-263: the host draws the positions).  Samples
+ * are appended in raster order / list order, as the reference pushes them. */
+int ife_samples_add_features(ife_ctx *ctx, ife_samples *s, int first_column,
+                             const float *features, int layout, int ncomp, const void *mask,
+                             int mask_dtype, int64_t nvox, const uint32_t *foreground,
+                             int n_foreground, const int64_t *indices, int64_t n_indices,
+                             int mem);
+
+/* One image of the tool's loop (:176-265): the labels are clamped to {0,1} for the filter
+ * (ClampImageFilter, :147-152), a5 runs at every scale with its output left in HBM, and
+ * the samples of scale i go to columns [8i, 8i+8).  The samples object must have
+ * 8*n_sigmas columns.  indices, when given, holds n_sigmas * n_indices_per_scale voxel
+ * indices, scale-major. */
+int ife_samples_add_image(ife_ctx *ctx, ife_samples *s, const void *image, int image_dtype,
+                          const void *mask, int mask_dtype, const ife_volume_desc *vol,
+                          const float *sigmas, int n_sigmas, const uint32_t *foreground,
+                          int n_foreground, const int64_t *indices,
+                          int64_t n_indices_per_scale, int mem);
+
+/* :282-289: sort every column and write its equalizing edges; edges is a HOST array of
+ * n_columns * (nbins-1) floats, one row per column in column order. */
+int ife_samples_sort(ife_ctx *ctx, ife_samples *s);
+int ife_samples_equalized_edges(ife_ctx *ctx, ife_samples *s, int nbins, float *edges);
+/* copy one column (count values) to a HOST array */
+int ife_samples_read_column(ife_ctx *ctx, const ife_samples *s, int column, float *out,
+                            int64_t capacity);
+
 /* ---- measurement ------------------------------------------------------------------- */
 
 #define IFE_MAX_KERNEL_KINDS 16

@@ -550,3 +550,105 @@ void ife_or_mask_image_f64(const double *image, const double *mask, double outsi
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) out[i] = (mask[i] != 0.0) ? image[i] : outside;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* f1: include/ife/Statistics/DetermineEdgesForEqualizedHistogram.h:21-137, on indices   */
+/* ------------------------------------------------------------------------------------ */
+#define IFE_OR_EDGES(NAME, T)                                                               \
+  int NAME(const T *v, int64_t n, int64_t nbins, T *edges) {                                \
+    if (n < 0) return 2;               /* :31-33 */                                         \
+    if (n < nbins) return 1;           /* :36-38 */                                         \
+    if (nbins < 1) return 1;                                                                \
+    const int64_t per_bin = n / nbins; /* :40 */                                            \
+    int64_t surplus = n - per_bin * nbins, deficit = 0, nedge = 0, it = 0; /* :41-44 */     \
+    while (nedge + 1 < nbins) {        /* :45 */                                            \
+      int64_t index = per_bin;                                                              \
+      if (surplus) {                   /* :50-58 */                                         \
+        int64_t take = surplus / (nbins - nedge);                                           \
+        if (take == 0) take = 1;                                                            \
+        index += take;                                                                      \
+        surplus -= take;                                                                    \
+      } else if (deficit) {            /* :59-67 */                                         \
+        int64_t take = deficit / (nbins - nedge);                                           \
+        if (take == 0) take = 1;                                                            \
+        index -= take;                                                                      \
+        deficit -= take;                                                                    \
+      }                                                                                     \
+      if (!(n - it > index)) return 3; /* assert :74 */                                     \
+      it += index;                     /* :75 */                                            \
+      const T x = v[it];                                                                    \
+      int64_t lo = 0, hi = it;         /* lower_bound(first, it, *it) :82 */                \
+      while (lo < hi) {                                                                     \
+        const int64_t mid = lo + (hi - lo) / 2;                                             \
+        if (v[mid] < x) lo = mid + 1; else hi = mid;                                        \
+      }                                                                                     \
+      const int64_t lb = lo;                                                                \
+      if (lb != it) {                  /* :86 */                                            \
+        lo = it; hi = n;               /* upper_bound(it, last, *it) :88 */                 \
+        while (lo < hi) {                                                                   \
+          const int64_t mid = lo + (hi - lo) / 2;                                           \
+          if (!(x < v[mid])) lo = mid + 1; else hi = mid;                                   \
+        }                                                                                   \
+        const int64_t ub = lo;                                                              \
+        if (ub == n) {                 /* :90-95 */                                         \
+          it = lb;                                                                          \
+        } else {                                                                            \
+          const int64_t lbdist = it - lb, ubdist = ub - it; /* :102-108 */                  \
+          if (lbdist < ubdist || (lbdist == ubdist && deficit)) { /* :116-124 */            \
+            it = lb;                                                                        \
+            if (lbdist > deficit) { surplus = lbdist - deficit; deficit = 0; }              \
+            else deficit -= lbdist;                                                         \
+          } else {                     /* :125-134 */                                       \
+            it = ub;                                                                        \
+            if (ubdist > surplus) { deficit = ubdist - surplus; surplus = 0; }              \
+            else surplus -= ubdist;                                                         \
+          }                                                                                 \
+        }                                                                                   \
+      }                                                                                     \
+      edges[nedge++] = v[it];          /* :138-139 */                                       \
+    }                                                                                       \
+    return 0;                                                                               \
+  }
+IFE_OR_EDGES(ife_or_equalized_edges_f32, float)
+IFE_OR_EDGES(ife_or_equalized_edges_f64, double)
+
+static int cmp_f32(const void *a, const void *b) {
+  const float x = *(const float *)a, y = *(const float *)b;
+  return (x > y) - (x < y);
+}
+/* tools/DetermineHistogramBinEdges_MultiScaleEigenvalueFeatures.cxx:284 */
+void ife_or_sort_f32(float *v, int64_t n) { qsort(v, (size_t)n, sizeof(float), cmp_f32); }
+
+/* same tool, :221-236 (nSamples == 0): raster order, first matching foreground value wins */
+int64_t ife_or_gather_foreground(const float *features, int ncomp, const uint8_t *mask,
+                                 int64_t nvox, const uint32_t *fg, int nfg, float **columns) {
+  int64_t m = 0;
+  for (int64_t i = 0; i < nvox; ++i) {
+    int hit = 0;
+    for (int k = 0; k < nfg && !hit; ++k) hit = ((uint32_t)mask[i] == fg[k]);
+    if (!hit) continue;
+    if (columns)
+      for (int c = 0; c < ncomp; ++c) columns[c][m] = features[i * ncomp + c];
+    ++m;
+  }
+  return m;
+}
+
+/* f2: include/ife/Statistics/DenseHistogram.h:47-60 */
+void ife_or_dense_histogram_f32(const float *edges, int64_t nedges, const float *values,
+                                int64_t n, uint32_t *counts, float *freqs) {
+  for (int64_t b = 0; b <= nedges; ++b) counts[b] = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t lo = 0, hi = nedges; /* lower_bound(edges, value): first edge >= value (:48) */
+    while (lo < hi) {
+      const int64_t mid = lo + (hi - lo) / 2;
+      if (edges[mid] < values[i]) lo = mid + 1; else hi = mid;
+    }
+    ++counts[lo];
+  }
+  /* getFrequencies :55-60: the sum accumulates in int (the literal 0), then becomes float */
+  int sum = 0;
+  for (int64_t b = 0; b <= nedges; ++b) sum = (int)(sum + counts[b]);
+  const float fsum = (float)sum;
+  for (int64_t b = 0; b <= nedges; ++b) freqs[b] = (float)counts[b] / fsum;
+}

@@ -99,6 +99,31 @@ int ife_or_fd_gradient_features(const float *image, const float *mask, float *ou
 void ife_or_mask_image_f64(const double *image, const double *mask, double outside,
                            double *out, int64_t n);
 
+/* ---- rows f1/f2 (histogram edges and dense histograms).  PINNED: the reference's own
+ * headers for these compile here (oracle/_ref, `make -C oracle _ref`) and its tests hold
+ * known answers (test/DetermineEdgesForEqualizedHistogramTest.cxx:30-72,
+ * test/DenseHistogramTest.cxx:10-55); tests/test_oracle_stats.py checks the restatement
+ * against both and against tests/golden/stats_*.json generated from oracle/_ref. ---- */
+
+/* f1: determineEdgesForEqualizedHistogram, include/ife/Statistics/
+ * DetermineEdgesForEqualizedHistogram.h:21-137.  sorted[0..n) ascending; writes nbins-1
+ * edges.  Returns 0; 1 when n < nbins (std::out_of_range there, :36-38); 3 when the walk
+ * would step to or past the end (assert at :74; undefined behaviour in a release build
+ * of the reference, an error here). */
+int ife_or_equalized_edges_f32(const float *sorted, int64_t n, int64_t nbins, float *edges);
+int ife_or_equalized_edges_f64(const double *sorted, int64_t n, int64_t nbins, double *edges);
+/* std::sort of one sample column (tools/DetermineHistogramBinEdges_MultiScaleEigenvalueFeatures.cxx:284) */
+void ife_or_sort_f32(float *v, int64_t n);
+/* the all-foreground sample gather of the same tool (:221-236): for every voxel whose mask
+ * value equals one of fg[0..nfg), append its ncomp interleaved feature values to the
+ * ncomp columns; columns[c] must hold the number of such voxels (returned). */
+int64_t ife_or_gather_foreground(const float *features, int ncomp, const uint8_t *mask,
+                                 int64_t nvox, const uint32_t *fg, int nfg, float **columns);
+/* f2: DenseHistogram<float> (include/ife/Statistics/DenseHistogram.h:29-66): bins
+ * (-inf,e0], (e0,e1], ..., (e_last, inf); counts and freqs hold nedges+1 entries. */
+void ife_or_dense_histogram_f32(const float *edges, int64_t nedges, const float *values,
+                                int64_t n, uint32_t *counts, float *freqs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -209,3 +209,139 @@ def mask_image_f64(image, mask, outside=0.0):
     lib().ife_or_mask_image_f64(_p(image, C.c_double), _p(mask, C.c_double), C.c_double(outside),
                                 _p(out, C.c_double), C.c_int64(image.size))
     return out
+
+
+# ---- rows f1 / f2: histogram edges and dense histograms ----
+
+class EdgeWalkError(RuntimeError):
+    """rc 1: fewer samples than bins (std::out_of_range in the reference); rc 3: the walk
+    would run past the last sample (an assert in the reference)."""
+
+    def __init__(self, rc):
+        RuntimeError.__init__(self, "equalized edges rc=%d" % rc)
+        self.rc = rc
+
+
+def equalized_edges(sorted_values, nbins):
+    """determineEdgesForEqualizedHistogram on an ascending float32/float64 array."""
+    v = np.ascontiguousarray(sorted_values)
+    if v.dtype == np.float64:
+        out = np.empty(max(nbins - 1, 0), np.float64)
+        rc = lib().ife_or_equalized_edges_f64(_p(v, C.c_double), C.c_int64(v.size),
+                                              C.c_int64(nbins), _p(out, C.c_double))
+    else:
+        v = np.ascontiguousarray(v, np.float32)
+        out = np.empty(max(nbins - 1, 0), np.float32)
+        rc = lib().ife_or_equalized_edges_f32(_p(v, C.c_float), C.c_int64(v.size),
+                                              C.c_int64(nbins), _p(out, C.c_float))
+    if rc != 0:
+        raise EdgeWalkError(rc)
+    return out
+
+
+def sort_f32(values):
+    v = np.array(values, np.float32).ravel()
+    lib().ife_or_sort_f32(_p(v, C.c_float), C.c_int64(v.size))
+    return v
+
+
+def gather_foreground(features, mask, foreground):
+    """features (..., ncomp) interleaved float32, mask uint8 -> (ncomp, m) sample columns."""
+    features = np.ascontiguousarray(features, np.float32)
+    mask = np.ascontiguousarray(mask, np.uint8)
+    ncomp = features.shape[-1]
+    fg = np.ascontiguousarray(foreground, np.uint32)
+    f = lib().ife_or_gather_foreground
+    f.restype = C.c_int64
+    m = f(_p(features, C.c_float), C.c_int(ncomp), _p(mask, C.c_uint8), C.c_int64(mask.size),
+          _p(fg, C.c_uint32), C.c_int(fg.size), None)
+    cols = np.empty((ncomp, m), np.float32)
+    ptrs = (C.POINTER(C.c_float) * ncomp)(*[_p(cols[c], C.c_float) for c in range(ncomp)])
+    f(_p(features, C.c_float), C.c_int(ncomp), _p(mask, C.c_uint8), C.c_int64(mask.size),
+      _p(fg, C.c_uint32), C.c_int(fg.size), ptrs)
+    return cols
+
+
+def dense_histogram(edges, values):
+    edges = np.ascontiguousarray(edges, np.float32)
+    values = np.ascontiguousarray(values, np.float32).ravel()
+    counts = np.empty(edges.size + 1, np.uint32)
+    freqs = np.empty(edges.size + 1, np.float32)
+    lib().ife_or_dense_histogram_f32(_p(edges, C.c_float), C.c_int64(edges.size),
+                                     _p(values, C.c_float), C.c_int64(values.size),
+                                     _p(counts, C.c_uint32), _p(freqs, C.c_float))
+    return counts, freqs
+
+
+# ---- oracle/_ref: the reference's own statistics / IO headers, compiled in place ----
+
+_REF_PATH = os.path.join(_HERE, "_ref", "libife_ref_stats.so")
+_ref = None
+
+
+def build_ref():
+    """`make -C oracle _ref`: builds only where /root/reference exists."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "_ref"])
+
+
+def ref_lib():
+    """The compiled reference (or None where neither it nor /root/reference is present)."""
+    global _ref
+    if _ref is None:
+        if not os.path.exists(_REF_PATH):
+            build_ref()
+        if not os.path.exists(_REF_PATH):
+            return None
+        _ref = C.CDLL(_REF_PATH)
+    return _ref
+
+
+def ref_equalized_edges(sorted_values, nbins):
+    """Call the reference template itself.  Only for inputs on which equalized_edges()
+    succeeds: the reference asserts (aborts) where that returns rc 3."""
+    v = np.ascontiguousarray(sorted_values)
+    r = ref_lib()
+    if v.dtype == np.float64:
+        out = np.empty(max(nbins - 1, 0), np.float64)
+        rc = r.ife_ref_edges_f64(_p(v, C.c_double), C.c_size_t(v.size), C.c_size_t(nbins),
+                                 _p(out, C.c_double))
+    else:
+        v = np.ascontiguousarray(v, np.float32)
+        out = np.empty(max(nbins - 1, 0), np.float32)
+        rc = r.ife_ref_edges_f32(_p(v, C.c_float), C.c_size_t(v.size), C.c_size_t(nbins),
+                                 _p(out, C.c_float))
+    if rc != 0:
+        raise EdgeWalkError(rc)
+    return out
+
+
+def ref_dense_histogram(edges, values):
+    edges = np.ascontiguousarray(edges, np.float32)
+    values = np.ascontiguousarray(values, np.float32).ravel()
+    counts = np.empty(edges.size + 1, np.uint32)
+    freqs = np.empty(edges.size + 1, np.float32)
+    ref_lib().ife_ref_dense_histogram_f32(_p(edges, C.c_float), C.c_size_t(edges.size),
+                                          _p(values, C.c_float), C.c_size_t(values.size),
+                                          _p(counts, C.c_uint32), _p(freqs, C.c_float))
+    return counts, freqs
+
+
+def ref_write_sequence(values, sep=","):
+    v = np.ascontiguousarray(values, np.float32).ravel()
+    buf = C.create_string_buffer(32 * v.size + 16)
+    n = ref_lib().ife_ref_write_sequence_f32(_p(v, C.c_float), C.c_size_t(v.size),
+                                             C.c_char(sep.encode()), buf, C.c_size_t(len(buf)))
+    if n < 0:
+        raise RuntimeError("buffer too small")
+    return buf.value.decode()
+
+
+def ref_read_pair_list(path, sep=","):
+    buf = C.create_string_buffer(1 << 16)
+    n = ref_lib().ife_ref_read_pair_list(path.encode(), C.c_char(sep.encode()), buf,
+                                         C.c_size_t(len(buf)))
+    if n == -2:
+        raise ValueError("Line does not contain a separator")
+    if n < 0:
+        raise RuntimeError("buffer too small")
+    return [tuple(line.split("\t")) for line in buf.value.decode().splitlines()]
