@@ -40,7 +40,7 @@ EXPORTS = (
     "ife_get_kernel_times", "ife_reset_kernel_times",
     "ife_stage_prepare", "ife_stage_recursive_gaussian", "ife_stage_recursive_gaussian_batch",
     "ife_stage_features",
-    "ife_sort_f32", "ife_equalized_edges_f32", "ife_dense_histogram_f32",
+    "ife_sort_f32", "ife_equalized_edges_f32", "ife_equalized_edges_f64", "ife_dense_histogram_f32",
     "ife_samples_create", "ife_samples_destroy", "ife_samples_count", "ife_samples_clear",
     "ife_samples_add_features", "ife_samples_add_image", "ife_samples_sort",
     "ife_samples_equalized_edges", "ife_samples_read_column",
@@ -106,6 +106,7 @@ def load_library():
     lib.ife_reset_kernel_times.argtypes = [vp]
     lib.ife_sort_f32.argtypes = [vp, vp, i64, vp, i32]
     lib.ife_equalized_edges_f32.argtypes = [vp, vp, i64, i32, vp, i32]
+    lib.ife_equalized_edges_f64.argtypes = [vp, vp, i64, i32, vp, i32]
     lib.ife_dense_histogram_f32.argtypes = [vp, vp, i32, vp, i64, vp, i32]
     lib.ife_samples_create.argtypes = [vp, i32, C.POINTER(vp)]
     lib.ife_samples_destroy.argtypes = [vp]
@@ -353,8 +354,14 @@ class Context:
                                          MEM_DEVICE))
 
     def equalized_edges(self, sorted_values, nbins):
-        """determineEdgesForEqualizedHistogram on an ascending float32 array."""
-        v = np.ascontiguousarray(sorted_values, np.float32).ravel()
+        """determineEdgesForEqualizedHistogram on an ascending float32 (or float64) array."""
+        v = np.ascontiguousarray(sorted_values)
+        if v.dtype == np.float64:
+            out = np.empty(max(int(nbins) - 1, 0), np.float64)
+            self._chk(self._lib.ife_equalized_edges_f64(self._h, v.ctypes.data, v.size, int(nbins),
+                                                        out.ctypes.data, MEM_HOST))
+            return out
+        v = np.ascontiguousarray(v, np.float32).ravel()
         out = np.empty(max(int(nbins) - 1, 0), np.float32)
         self._chk(self._lib.ife_equalized_edges_f32(self._h, v.ctypes.data, v.size, int(nbins),
                                                     out.ctypes.data, MEM_HOST))

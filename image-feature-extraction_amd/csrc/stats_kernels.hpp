@@ -173,7 +173,9 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(
   const uint32_t *src = in + (int64_t)col * g.stride;
   uint32_t *dst = out + (int64_t)col * g.stride;
   uint32_t gofs = table[((int64_t)col * g.ntiles + tile) * 256 + tid];  // thread = digit
-  volatile uint32_t *wcnt = cnt[wave];
+  // LDS pointer kept in its address space (a generic pointer would turn these into flat ops)
+  typedef __attribute__((address_space(3))) volatile uint32_t lds_u32;
+  lds_u32 *wcnt = (lds_u32 *)&cnt[wave][0];
 
   for (int sub = 0; sub < SORT_SUB; ++sub) {
     const int64_t base = (int64_t)tile * SORT_TILE + (int64_t)sub * SORT_SUBTILE;
@@ -199,11 +201,11 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(
       uint64_t peers = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t bal = __builtin_amdgcn_ballot_w64(bit);
-        const uint32_t inv = bit ? 0u : ~0u;  // lanes that share the bit: bal ^ inv
-        const uint32_t lo = (uint32_t)bal ^ inv, hi = (uint32_t)(bal >> 32) ^ inv;
-        peers &= ((uint64_t)hi << 32) | lo;
+        const int32_t sx = (int32_t)(key[r] << (31 - b - shift));  // digit bit b in the sign
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(sx < 0);
+        const uint32_t same = (uint32_t)(sx >> 31);  // ~0 where the bit is set
+        const uint32_t lo = ~((uint32_t)bal ^ same), hi = ~((uint32_t)(bal >> 32) ^ same);
+        peers &= ((uint64_t)hi << 32) | lo;  // lanes whose bit equals this lane's
       }
       const uint32_t below = lanes_below(peers);
       const uint32_t seen = wcnt[d];
@@ -379,14 +381,15 @@ __global__ __launch_bounds__(256) void clamp01_kernel(const TM *__restrict__ in,
 // column per workgroup; the walk is sequential (each edge depends on the surplus / deficit
 // the previous one left), so lane 0 walks and the binary searches are its dependent loads.
 // status[col]: 0 ok, 1 fewer samples than bins (:36-38), 3 walk past the end (assert :74).
-__global__ __launch_bounds__(64) void equalized_edges_kernel(const float *__restrict__ cols,
+template <typename T>
+__global__ __launch_bounds__(64) void equalized_edges_kernel(const T *__restrict__ cols,
                                                              int64_t col_stride, int64_t n,
-                                                             int nbins_i, float *__restrict__ edges,
+                                                             int nbins_i, T *__restrict__ edges,
                                                              int *__restrict__ status) {
   if (threadIdx.x != 0) return;
   const int col = blockIdx.x;
-  const float *v = cols + (int64_t)col * col_stride;
-  float *e = edges + (int64_t)col * (nbins_i - 1);
+  const T *v = cols + (int64_t)col * col_stride;
+  T *e = edges + (int64_t)col * (nbins_i - 1);
   const int64_t nbins = nbins_i;
   if (n < nbins) { status[col] = 1; return; }
   const int64_t per_bin = n / nbins;
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(64) void equalized_edges_kernel(const float *__rest
     }
     if (!(n - it > index)) { status[col] = 3; return; }
     it += index;
-    const float x = v[it];
+    const T x = v[it];
     int64_t lo = 0, hi = it;
     while (lo < hi) {
       const int64_t mid = lo + (hi - lo) / 2;

@@ -4,13 +4,18 @@
 // in tests/golden/eigen_kat.json), and error translation.  Exit code 0 = pass.
 #include <cmath>
 #include <cstdio>
+#include <fstream>
 #include <iostream>
+#include <sstream>
 
 #include "ife/Filters/Hessian3DImageFilter.h"
 #include "ife/Filters/ImageToEmphysemaFeaturesFilter.h"
 #include "ife/Filters/NormalizedGaussianConvolutionImageFilter.h"
 #include "ife/Host/ImageIO.h"
 #include "ife/Host/LiteFilters.h"
+#include "ife/IO/IO.h"
+#include "ife/Statistics/DenseHistogram.h"
+#include "ife/Statistics/DetermineEdgesForEqualizedHistogram.h"
 #include "ife/Numerics/EigenvalueFeaturesFunctor.h"
 #include "ife/Util/Path.h"
 
@@ -159,6 +164,57 @@ int main(int argc, char **argv) {
     bool threw = false;
     try { bad->Update(); } catch (itk::ExceptionObject &e) { threw = std::string(e.what()).find("at least 4") != std::string::npos; }
     CHECK(threw);
+
+    // rows f1 / f2 through the reference's own interfaces, on its own known answers
+    // (test/DetermineEdgesForEqualizedHistogramTest.cxx:30-70, test/DenseHistogramTest.cxx:10-55)
+    {
+      std::vector<double> values{1, 2, 3, 4, 5, 6, 7, 8, 9}, edges(2);
+      determineEdgesForEqualizedHistogram(values.begin(), values.end(), edges.begin(), 3);
+      CHECK(edges[0] == 4 && edges[1] == 7);
+      std::vector<double> same(8, 1), e1{0, 123};
+      determineEdgesForEqualizedHistogram(same.begin(), same.end(), e1.begin(), 2);
+      CHECK(e1[0] == 1 && e1[1] == 123);
+      std::vector<float> uneven{1, 1, 1, 1, 1, 2, 2, 3, 3, 3}, e2;
+      determineEdgesForEqualizedHistogram(uneven.begin(), uneven.end(), std::back_inserter(e2), 3);
+      CHECK(e2.size() == 2 && e2[0] == 2 && e2[1] == 3);
+      bool range = false;
+      std::vector<double> e9(9);
+      try { determineEdgesForEqualizedHistogram(values.begin(), values.end(), e9.begin(), 10); }
+      catch (const std::out_of_range &) { range = true; }
+      CHECK(range);
+
+      const float vals[18] = {-1, 0, 0.5f, 1, 1.5f, 2.1f, 2.6f, 2.9f, 3.2f, 3.5f, 4.2f, 4.6f, 5, 6, 7, 8, 9, 10};
+      DenseHistogram<float> hist({1, 2.5f, 3.0f, 4.7f, 6.2f, 8.3f});
+      for (float v : vals) hist.insert(v);
+      const unsigned int expected[7] = {4, 2, 2, 4, 2, 2, 2};
+      const std::vector<unsigned int> counts = hist.getCounts();
+      const std::vector<float> freq = hist.getFrequencies();
+      CHECK(counts.size() == 7 && hist.getNumberOfBins() == 7);
+      for (size_t i = 0; i < 7 && i < counts.size(); ++i) {
+        CHECK(counts[i] == expected[i]);
+        CHECK(std::fabs(freq[i] - expected[i] / 18.0f) < 1e-7f);
+      }
+      std::ostringstream os;
+      os << hist;
+      CHECK(os.str() == "4,2,2,4,2,2,2");
+      hist.resetCounts();
+      hist.insert(100.0f);
+      CHECK(hist.getCounts()[6] == 1 && hist.getCounts()[0] == 0);
+
+      std::ostringstream row;
+      const float fr[6] = {1.5f, -0.0f, 1e-7f, 123456789.0f, 3.1415927f, 1e10f};
+      writeSequenceAsText(row, fr, fr + 6);
+      CHECK(row.str() == "1.5,-0,1e-07,1.23457e+08,3.14159,1e+10");  // tests/golden/stats_ref.json
+      const std::string list = tmp + "/ife_selftest_pairs.csv";
+      { std::ofstream f(list.c_str()); f << "a.nii.gz, m a.nii.gz \n\n b.nii,b_mask.nii\r\n"; }
+      const std::vector<StringPair> pairs = readPairList(list);
+      CHECK(pairs.size() == 2 && pairs[0].first == "a.nii.gz" && pairs[0].second == "m a.nii.gz");
+      CHECK(pairs.size() == 2 && pairs[1].first == "b.nii" && pairs[1].second == "b_mask.nii");
+      { std::ofstream f(list.c_str()); f << "no separator here\n"; }
+      bool inv = false;
+      try { readPairList(list); } catch (const std::invalid_argument &) { inv = true; }
+      CHECK(inv);
+    }
   } catch (itk::ExceptionObject &e) {
     std::cout << "unexpected " << e << std::endl;
     return 2;

@@ -237,6 +237,10 @@ int ife_sort_f32(ife_ctx *ctx, const float *in, int64_t n, float *out, int mem);
  * :36-38); IFE_E_STATE when the walk would pass the last sample (an assert there, :74). */
 int ife_equalized_edges_f32(ife_ctx *ctx, const float *sorted, int64_t n, int nbins,
                             float *edges, int mem);
+/* the same on doubles (the reference's own test instantiates the template on double,
+ * test/DetermineEdgesForEqualizedHistogramTest.cxx:11) */
+int ife_equalized_edges_f64(ife_ctx *ctx, const double *sorted, int64_t n, int nbins,
+                            double *edges, int mem);
 
 /* DenseHistogram<float>: insert every value, getCounts
  * (include/ife/Statistics/DenseHistogram.h:29-64).  Bins (-inf,e0], (e0,e1], ...,

@@ -62,9 +62,10 @@ def test_sort_large(ctx):
 
 def test_edges_reference_known_answers(ctx, ife):
     # test/DetermineEdgesForEqualizedHistogramTest.cxx:30-70
-    assert ctx.equalized_edges(np.arange(1, 10), 3).tolist() == [4.0, 7.0]
-    assert ctx.equalized_edges(np.ones(8), 2).tolist() == [1.0]
-    assert ctx.equalized_edges([1, 1, 1, 1, 1, 2, 2, 3, 3, 3], 3).tolist() == [2.0, 3.0]
+    for dt in (np.float32, np.float64):  # the reference's test runs the template on double
+        assert ctx.equalized_edges(np.arange(1, 10, dtype=dt), 3).tolist() == [4.0, 7.0]
+        assert ctx.equalized_edges(np.ones(8, dt), 2).tolist() == [1.0]
+        assert ctx.equalized_edges(np.array([1, 1, 1, 1, 1, 2, 2, 3, 3, 3], dt), 3).tolist() == [2.0, 3.0]
     with pytest.raises(ife.IfeError) as ei:
         ctx.equalized_edges(np.arange(1, 10), 10)
     assert ei.value.code == ife.E_ARG and "Too many bins" in str(ei.value)
@@ -80,6 +81,8 @@ def test_edges_reference_fixtures(ctx, ife):
                 ctx.equalized_edges(v, c["nbins"])
             continue
         assert np.array_equal(ctx.equalized_edges(v, c["nbins"]), unhex(c["edges_f32"])), c["kind"]
+        assert np.array_equal(ctx.equalized_edges(v.astype(np.float64), c["nbins"]),
+                              unhex(c["edges_f64"], np.float64)), c["kind"]
 
 
 def test_edges_random_against_oracle_and_compiled_reference(ctx, ife, oracle):

@@ -43,6 +43,15 @@ def test_usage_and_argument_errors(built, tool):
     assert r.returncode == 1 and "Couldn't find match" in r.stderr
 
 
+def test_edges_tool_usage(built):
+    tool = "DetermineHistogramBinEdges_MultiScaleEigenvalueFeatures"
+    h = run(tool, "--help")
+    assert h.returncode == 0
+    assert all(f in h.stdout for f in ("--infile", "--outfile", "--bins", "--samples", "--scale", "--foreground"))
+    r = run(tool, "-i", "x", "-o", "y")     # -b -S -s -f are required in the reference too
+    assert r.returncode == 1 and "Error :" in r.stderr
+
+
 def test_reference_flag_names(built):
     assert all(f in run("ExtractFeatures", "--help").stdout for f in ("-i,", "-m,", "-o,", "-s,", "--scale"))
     h = run("FiniteDifference_HessianFeatures", "--help").stdout
@@ -144,3 +153,57 @@ def test_fd_and_mask_tools(built, tmp_path, synth, oracle):
     vol, _ = niftiio.read(str(tmp_path / "masked.nii"))
     assert vol.dtype == np.float64
     np.testing.assert_array_equal(vol, np.where(mask != 0, img.astype(np.float64), -3.5))
+
+
+@pytest.mark.gpu
+def test_histogram_edges_tool(built, tmp_path, synth, oracle):
+    """All-foreground branch against the oracle doing the tool's steps on the CPU; output
+    format of tools/DetermineHistogramBinEdges_MultiScaleEigenvalueFeatures.cxx:270-296."""
+    tool = "DetermineHistogramBinEdges_MultiScaleEigenvalueFeatures"
+    scales, fg, nbins = [1.0, 2.5], (1, 2), 11
+    cols = [[] for _ in range(16)]
+    lines = []
+    for k, shape in enumerate([(16, 20, 24), (12, 28, 20)]):
+        img = synth.volume_f32(shape, 300 + k)
+        lab = synth.mask_ellipsoids(shape)
+        niftiio.write(str(tmp_path / ("img%d.nii.gz" % k)), img)
+        niftiio.write(str(tmp_path / ("lab%d.nii.gz" % k)), lab)
+        lines.append("%s , %s" % (tmp_path / ("img%d.nii.gz" % k), tmp_path / ("lab%d.nii.gz" % k)))
+        for i, sg in enumerate(scales):
+            g = oracle.gather_foreground(oracle.emphysema_features(img, np.minimum(lab, 1).astype(np.uint8), sg),
+                                         lab, fg)
+            for c in range(8):
+                cols[i * 8 + c].append(g[c])
+    (tmp_path / "pairs.csv").write_text("\n".join(lines) + "\n\n")
+    out = tmp_path / "edges.txt"
+    args = ["-i", str(tmp_path / "pairs.csv"), "-o", str(out), "-b", str(nbins), "-s", "1", "-s", "2.5",
+            "-f", "1", "-f", "2"]
+    r = run(tool, *args, "-S", "0")
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("Processing") == 2
+    text = out.read_text().splitlines()
+    assert text[0] == ("# Features: GaussianBlur GradientMagnitude Eigenvalue1 Eigenvalue2 Eigenvalue3 "
+                       "LaplacianOfGaussian GaussianCurvature FrobeniusNorm")
+    assert text[1] == "# Scales: 1 2.5"
+    assert len(text) == 2 + 16
+    for c in range(16):
+        want = oracle.equalized_edges(oracle.sort_f32(np.concatenate(cols[c])), nbins)
+        assert text[2 + c] == ",".join("%g" % v for v in want), c
+    # sampled branch: deterministic under IFE_SEED, edges non-decreasing and inside the range
+    env = dict(os.environ, IFE_SEED="7")
+    outs = []
+    for rep in range(2):
+        o = tmp_path / ("edges_s%d.txt" % rep)
+        a = [x if x != str(out) else str(o) for x in args]
+        rr = subprocess.run([os.path.join(BIN, tool)] + a + ["-S", "500"], capture_output=True, text=True, env=env)
+        assert rr.returncode == 0, rr.stderr
+        outs.append(o.read_text())
+    assert outs[0] == outs[1]
+    rows = [np.array([float(x) for x in ln.split(",")]) for ln in outs[0].splitlines()[2:]]
+    assert len(rows) == 16 and all(r_.size == nbins - 1 and np.all(np.diff(r_) >= 0) for r_ in rows)
+    for c in range(16):
+        allv = np.concatenate(cols[c])
+        assert rows[c][0] >= allv.min() - 1e-3 * abs(allv.min()) and rows[c][-1] <= allv.max() + 1e-3 * abs(allv.max())
+    # more bins than samples: the reference throws std::out_of_range; here a message and EXIT_FAILURE
+    bad = run(tool, *[x if x != str(nbins) else "100000" for x in args], "-S", "10")
+    assert bad.returncode == 1 and "Too many bins" in bad.stderr
