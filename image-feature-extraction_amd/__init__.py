@@ -40,7 +40,7 @@ EXPORTS = (
     "ife_get_kernel_times", "ife_reset_kernel_times",
     "ife_stage_prepare", "ife_stage_recursive_gaussian", "ife_stage_recursive_gaussian_batch",
     "ife_stage_features",
-    "ife_sort_f32", "ife_equalized_edges_f32", "ife_equalized_edges_f64", "ife_dense_histogram_f32",
+    "ife_sort_f32", "ife_equalized_edges_f32", "ife_equalized_edges_f64", "ife_dense_histogram_f32", "ife_roi_histograms", "ife_bag_image",
     "ife_samples_create", "ife_samples_destroy", "ife_samples_count", "ife_samples_clear",
     "ife_samples_add_features", "ife_samples_add_image", "ife_samples_sort",
     "ife_samples_equalized_edges", "ife_samples_read_column",
@@ -108,6 +108,9 @@ def load_library():
     lib.ife_equalized_edges_f32.argtypes = [vp, vp, i64, i32, vp, i32]
     lib.ife_equalized_edges_f64.argtypes = [vp, vp, i64, i32, vp, i32]
     lib.ife_dense_histogram_f32.argtypes = [vp, vp, i32, vp, i64, vp, i32]
+    lib.ife_roi_histograms.argtypes = [vp, vp, i32, i32, vp, i32, vd, vp, i32, vp, i32, vp, i32]
+    lib.ife_bag_image.argtypes = [vp, vp, i32, vp, i32, vd, C.POINTER(C.c_float), i32, vp, i32, vp,
+                                  i32, vp, i32]
     lib.ife_samples_create.argtypes = [vp, i32, C.POINTER(vp)]
     lib.ife_samples_destroy.argtypes = [vp]
     lib.ife_samples_destroy.restype = None
@@ -373,6 +376,38 @@ class Context:
         counts = np.empty(e.size + 1, np.uint32)
         self._chk(self._lib.ife_dense_histogram_f32(self._h, e.ctypes.data, e.size, v.ctypes.data,
                                                     v.size, counts.ctypes.data, MEM_HOST))
+        return counts
+
+    def roi_histograms(self, features, mask, rois, edges, spacing=(1.0, 1.0, 1.0), layout=INTERLEAVED):
+        """Bag rows of one feature volume: counts (n_rois, ncomp, n_edges+1) uint32."""
+        f = np.ascontiguousarray(features, np.float32)
+        mask = np.ascontiguousarray(mask)
+        rois = np.ascontiguousarray(rois, np.int64).reshape(-1, 6)
+        edges = np.ascontiguousarray(edges, np.float32)
+        ncomp, ne = edges.shape
+        d = _desc(mask.shape, spacing)
+        counts = np.empty((rois.shape[0], ncomp, ne + 1), np.uint32)
+        self._chk(self._lib.ife_roi_histograms(
+            self._h, f.ctypes.data, layout, ncomp, mask.ctypes.data, _MSK_DT[mask.dtype], C.byref(d),
+            rois.ctypes.data, rois.shape[0], edges.ctypes.data, ne, counts.ctypes.data, MEM_HOST))
+        return counts
+
+    def bag_image(self, image, mask, sigmas, rois, edges, spacing=(1.0, 1.0, 1.0)):
+        """One image of MakeBag: counts (n_rois, n_sigmas*8, n_edges+1) uint32."""
+        image = np.ascontiguousarray(image)
+        if image.dtype not in _IMG_DT:
+            image = image.astype(np.float32)
+        mask = np.ascontiguousarray(mask)
+        rois = np.ascontiguousarray(rois, np.int64).reshape(-1, 6)
+        edges = np.ascontiguousarray(edges, np.float32)
+        ne = edges.shape[1]
+        d = _desc(image.shape, spacing)
+        sig = (C.c_float * len(sigmas))(*[float(s) for s in sigmas])
+        counts = np.empty((rois.shape[0], 8 * len(sigmas), ne + 1), np.uint32)
+        self._chk(self._lib.ife_bag_image(
+            self._h, image.ctypes.data, _IMG_DT[image.dtype], mask.ctypes.data, _MSK_DT[mask.dtype],
+            C.byref(d), sig, len(sigmas), rois.ctypes.data, rois.shape[0], edges.ctypes.data, ne,
+            counts.ctypes.data, MEM_HOST))
         return counts
 
     def samples(self, n_columns):

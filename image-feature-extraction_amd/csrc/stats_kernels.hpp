@@ -474,5 +474,56 @@ __global__ __launch_bounds__(256) void dense_histogram_kernel(const float *__res
     if (c[i]) atomicAdd(&counts[i], c[i]);
 }
 
+// ---- per-ROI histograms: the bag rows of tools/MakeBag.cxx:405-472 ---------------------------
+// grid (n_rois, ROI_SPLIT): each workgroup bins a z-range of one box for all components.
+// Edges [ncomp][nedges] and counters [ncomp][nedges+1] live in LDS; counts are merged with
+// global atomics (the host zeroes them first).
+constexpr int ROI_SPLIT = 8;
+constexpr int ROI_MAX_LDS_WORDS = 8192;  // ncomp * (2*nedges + 1) must fit
+struct RoiArgs {
+  int64_t nx, ny, nz;
+  int64_t feat_comp_stride, feat_vox_stride;
+  int ncomp, nedges;
+};
+template <typename TM>
+__global__ __launch_bounds__(256) void roi_histogram_kernel(const float *__restrict__ feat,
+                                                            const TM *__restrict__ mask,
+                                                            const int64_t *__restrict__ rois,
+                                                            const float *__restrict__ edges,
+                                                            unsigned int *__restrict__ counts,
+                                                            RoiArgs a) {
+  __shared__ float lds[ROI_MAX_LDS_WORDS];
+  const int nb = a.nedges + 1;
+  float *e = lds;
+  unsigned int *c = reinterpret_cast<unsigned int *>(lds + a.ncomp * a.nedges);
+  for (int i = threadIdx.x; i < a.ncomp * a.nedges; i += blockDim.x) e[i] = edges[i];
+  for (int i = threadIdx.x; i < a.ncomp * nb; i += blockDim.x) c[i] = 0;
+  __syncthreads();
+  const int64_t *q = rois + 6 * (int64_t)blockIdx.x;
+  const int64_t x0 = q[0], y0 = q[1], z0 = q[2], sx = q[3], sy = q[4], sz = q[5];
+  const int64_t zper = (sz + ROI_SPLIT - 1) / ROI_SPLIT;
+  const int64_t za = min((int64_t)blockIdx.y * zper, sz), zb = min(za + zper, sz);
+  const int64_t n = sx * sy * (zb - za);
+  for (int64_t t = threadIdx.x; t < n; t += blockDim.x) {
+    const int64_t x = t % sx, y = (t / sx) % sy, z = za + t / (sx * sy);
+    const int64_t i = (x0 + x) + a.nx * ((y0 + y) + a.ny * (z0 + z));
+    if (mask[i] == 0) continue;
+    for (int k = 0; k < a.ncomp; ++k) {
+      const float v = feat[k * a.feat_comp_stride + i * a.feat_vox_stride];
+      const float *ek = e + k * a.nedges;
+      int lo = 0, hi = a.nedges;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ek[mid] < v) lo = mid + 1; else hi = mid;
+      }
+      atomicAdd(&c[k * nb + lo], 1u);
+    }
+  }
+  __syncthreads();
+  unsigned int *out = counts + (int64_t)blockIdx.x * a.ncomp * nb;
+  for (int i = threadIdx.x; i < a.ncomp * nb; i += blockDim.x)
+    if (c[i]) atomicAdd(&out[i], c[i]);
+}
+
 }  // namespace ife
 #endif

@@ -62,19 +62,47 @@ struct Size3 {
   uint64_t &operator[](size_t i) { return v[i]; }
   const uint64_t &operator[](size_t i) const { return v[i]; }
 };
+inline std::ostream &operator<<(std::ostream &os, const Size3 &s) {  // as itk::Size prints
+  return os << "[" << s[0] << ", " << s[1] << ", " << s[2] << "]";
+}
+struct Index3 {
+  std::array<int64_t, 3> v{{0, 0, 0}};
+  int64_t &operator[](size_t i) { return v[i]; }
+  const int64_t &operator[](size_t i) const { return v[i]; }
+};
+inline std::ostream &operator<<(std::ostream &os, const Index3 &s) {  // as itk::Index prints
+  return os << "[" << s[0] << ", " << s[1] << ", " << s[2] << "]";
+}
 struct Spacing3 {
   std::array<double, 3> v{{1.0, 1.0, 1.0}};
   double &operator[](size_t i) { return v[i]; }
   const double &operator[](size_t i) const { return v[i]; }
 };
-struct Region3 {
+struct Region3 {  // itk::ImageRegion<3>: index + size
+  typedef Size3 SizeType;
+  typedef Index3 IndexType;
+  Index3 index;
   Size3 size;
+  Region3() = default;
+  Region3(const Index3 &i, const Size3 &s) : index(i), size(s) {}
   const Size3 &GetSize() const { return size; }
+  const Index3 &GetIndex() const { return index; }
   uint64_t GetNumberOfPixels() const { return size[0] * size[1] * size[2]; }
+  bool IsInside(const Region3 &r) const {  // r entirely inside this region
+    for (size_t d = 0; d < 3; ++d)
+      if (r.index[d] < index[d] || r.index[d] + (int64_t)r.size[d] > index[d] + (int64_t)size[d]) return false;
+    return true;
+  }
 };
+inline std::ostream &operator<<(std::ostream &os, const Region3 &r) {
+  return os << "ImageRegion Index: " << r.index << " Size: " << r.size;
+}
 
 class ImageBase3 {
  public:
+  typedef Size3 SizeType;
+  typedef Index3 IndexType;
+  typedef Region3 RegionType;
   virtual ~ImageBase3() {}
   void SetRegions(const Size3 &s) { region_.size = s; }
   const Region3 &GetLargestPossibleRegion() const { return region_; }

@@ -6,6 +6,7 @@
 
 #include <fstream>
 #include <iostream>
+#include <limits>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -24,6 +25,17 @@ std::ostream &writeSequenceAsText(std::ostream &out, InputIt begin, InputIt end,
     out << *it;
   }
   return out;
+}
+
+// Numbers separated by sep (the rows of a histogram specification, tools/MakeBag.cxx:330-332;
+// interface of IO.h:60-70): read while extraction succeeds, skipping through the next sep.
+template <typename ElemT, typename CharT, typename OutputIt>
+void readTextSequence(std::istream &is, OutputIt out, CharT sep = ',') {
+  ElemT elem;
+  while (is >> elem) {
+    *out++ = elem;
+    is.ignore(std::numeric_limits<std::streamsize>::max(), sep);
+  }
 }
 
 // One "image<sep>mask" pair per line; blank lines skipped; a line without the separator

@@ -248,6 +248,25 @@ int ife_equalized_edges_f64(ife_ctx *ctx, const double *sorted, int64_t n, int n
 int ife_dense_histogram_f32(ife_ctx *ctx, const float *edges, int n_edges, const float *values,
                             int64_t n, uint32_t *counts, int mem);
 
+/* Row f2: the bag rows of tools/MakeBag.cxx:405-472 for ONE feature volume.  rois holds
+ * n_rois boxes {x, y, z, sx, sy, sz} (index and size in voxels, as ROIReader.hxx:28-47 reads
+ * them); for every box and component c the component values of the box's voxels with
+ * mask != 0 are binned by edges[c*n_edges ..] (DenseHistogram bins), into
+ * counts[(roi*ncomp + c)*(n_edges+1) + bin].  IFE_E_ARG when a box leaves the volume
+ * (RegionOfInterestImageFilter throws there).  ncomp*(2*n_edges+1) <= 8192. */
+int ife_roi_histograms(ife_ctx *ctx, const float *features, int layout, int ncomp,
+                       const void *mask, int mask_dtype, const ife_volume_desc *vol,
+                       const int64_t *rois, int n_rois, const float *edges, int n_edges,
+                       uint32_t *counts, int mem);
+/* One image of MakeBag: labels clamped to {0,1} (:236-244), a5 at every scale with the
+ * features left in HBM, then the rows above per scale.  rois, edges ([n_sigmas*8][n_edges],
+ * the rows of the histogram specification) and counts
+ * ([n_rois][n_sigmas*8][n_edges+1]) are HOST arrays; mem describes image and mask. */
+int ife_bag_image(ife_ctx *ctx, const void *image, int image_dtype, const void *mask,
+                  int mask_dtype, const ife_volume_desc *vol, const float *sigmas, int n_sigmas,
+                  const int64_t *rois, int n_rois, const float *edges, int n_edges,
+                  uint32_t *counts, int mem);
+
 /* The tool's `samples( scales.size() * numFeatures )` (:165-166): one growing column per
  * (scale, feature), kept in device memory.  Belongs to the context it was created on. */
 typedef struct ife_samples ife_samples;

@@ -652,3 +652,45 @@ void ife_or_dense_histogram_f32(const float *edges, int64_t nedges, const float 
   const float fsum = (float)sum;
   for (int64_t b = 0; b <= nedges; ++b) freqs[b] = (float)counts[b] / fsum;
 }
+
+/* f2: tools/MakeBag.cxx:405-472 */
+int ife_or_roi_histograms(const float *features, int ncomp, const uint8_t *mask,
+                          const ife_or_dims *d, const int64_t *rois, int nrois,
+                          const float *edges, int64_t nedges, uint32_t *counts, float *freqs) {
+  const int64_t nb = nedges + 1;
+  for (int r = 0; r < nrois; ++r) {
+    const int64_t *q = rois + 6 * r;
+    if (q[0] < 0 || q[1] < 0 || q[2] < 0 || q[3] < 0 || q[4] < 0 || q[5] < 0 ||
+        q[0] + q[3] > d->nx || q[1] + q[4] > d->ny || q[2] + q[5] > d->nz)
+      return 4;
+  }
+  for (int r = 0; r < nrois; ++r) {
+    const int64_t *q = rois + 6 * r;
+    uint32_t *cr = counts + (int64_t)r * ncomp * nb;
+    for (int64_t k = 0; k < ncomp * nb; ++k) cr[k] = 0;
+    for (int64_t z = q[2]; z < q[2] + q[5]; ++z)
+      for (int64_t y = q[1]; y < q[1] + q[4]; ++y)
+        for (int64_t x = q[0]; x < q[0] + q[3]; ++x) {
+          const int64_t i = x + d->nx * (y + d->ny * z);
+          if (!mask[i]) continue; /* :438 */
+          for (int c = 0; c < ncomp; ++c) {
+            const float v = features[i * ncomp + c];
+            const float *e = edges + (int64_t)c * nedges;
+            int64_t lo = 0, hi = nedges;
+            while (lo < hi) {
+              const int64_t mid = lo + (hi - lo) / 2;
+              if (e[mid] < v) lo = mid + 1; else hi = mid;
+            }
+            ++cr[c * nb + lo];
+          }
+        }
+    for (int c = 0; c < ncomp; ++c) { /* getFrequencies, DenseHistogram.h:55-60 */
+      int sum = 0;
+      for (int64_t b = 0; b < nb; ++b) sum = (int)(sum + cr[c * nb + b]);
+      const float fsum = (float)sum;
+      for (int64_t b = 0; b < nb; ++b)
+        freqs[((int64_t)r * ncomp + c) * nb + b] = (float)cr[c * nb + b] / fsum;
+    }
+  }
+  return 0;
+}

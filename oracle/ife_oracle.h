@@ -124,6 +124,16 @@ int64_t ife_or_gather_foreground(const float *features, int ncomp, const uint8_t
 void ife_or_dense_histogram_f32(const float *edges, int64_t nedges, const float *values,
                                 int64_t n, uint32_t *counts, float *freqs);
 
+/* f2: the bag rows of tools/MakeBag.cxx:405-472 for one feature volume: for every box
+ * rois[r] = {x, y, z, sx, sy, sz} and component c, insert the component value of every
+ * voxel of the box whose mask is non-zero (raster order, :437-447) into a DenseHistogram
+ * with edges[c*nedges ..]; counts[(r*ncomp + c)*(nedges+1) + bin], freqs likewise
+ * (getFrequencies, :455-462; 0/0 = NaN for a box without mask voxels).  Returns 0, or 4 when
+ * a box leaves the volume (RegionOfInterestImageFilter throws there). */
+int ife_or_roi_histograms(const float *features, int ncomp, const uint8_t *mask,
+                          const ife_or_dims *d, const int64_t *rois, int nrois,
+                          const float *edges, int64_t nedges, uint32_t *counts, float *freqs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -273,6 +273,25 @@ def dense_histogram(edges, values):
     return counts, freqs
 
 
+def roi_histograms(features, mask, rois, edges):
+    """features (nz, ny, nx, ncomp), mask uint8, rois (n, 6) x,y,z,sx,sy,sz, edges (ncomp, ne)
+    -> counts (n, ncomp, ne+1) uint32, freqs float32: the bag rows of MakeBag for one scale."""
+    features = np.ascontiguousarray(features, np.float32)
+    mask = np.ascontiguousarray(mask, np.uint8)
+    rois = np.ascontiguousarray(rois, np.int64).reshape(-1, 6)
+    edges = np.ascontiguousarray(edges, np.float32)
+    ncomp, ne = edges.shape
+    d = _dims(mask.shape)
+    counts = np.empty((rois.shape[0], ncomp, ne + 1), np.uint32)
+    freqs = np.empty((rois.shape[0], ncomp, ne + 1), np.float32)
+    rc = lib().ife_or_roi_histograms(_p(features, C.c_float), C.c_int(ncomp), _p(mask, C.c_uint8),
+                                     C.byref(d), _p(rois, C.c_int64), C.c_int(rois.shape[0]),
+                                     _p(edges, C.c_float), C.c_int64(ne), _p(counts, C.c_uint32),
+                                     _p(freqs, C.c_float))
+    _chk(rc, "roi_histograms")
+    return counts, freqs
+
+
 # ---- oracle/_ref: the reference's own statistics / IO headers, compiled in place ----
 
 _REF_PATH = os.path.join(_HERE, "_ref", "libife_ref_stats.so")

@@ -209,3 +209,49 @@ def test_samples_errors(ctx, ife):
     with pytest.raises(ife.IfeError):
         s.add_image(np.zeros((4, 4, 4), np.float32), m, [1.0, 2.0])  # needs 16 columns
     s.close()
+
+
+# ---- row f2: the bag rows of MakeBag (tools/MakeBag.cxx:405-472) -------------------------------
+def random_rois(rng, shape, n, size):
+    nz, ny, nx = shape
+    sx, sy, sz = size
+    return np.stack([rng.integers(0, nx - sx + 1, n), rng.integers(0, ny - sy + 1, n),
+                     rng.integers(0, nz - sz + 1, n), np.full(n, sx), np.full(n, sy), np.full(n, sz)], 1)
+
+
+def test_roi_histograms_against_oracle(ctx, ife, oracle):
+    rng = np.random.default_rng(41)
+    shape = (18, 22, 26)
+    feat = np.round(rng.normal(0, 3, shape + (8,)), 1).astype(np.float32)  # values on edges happen
+    m = labels(shape, 42)
+    edges = np.sort(np.round(rng.normal(0, 3, (8, 13)), 1).astype(np.float32), axis=1)
+    rois = np.concatenate([random_rois(rng, shape, 9, (7, 5, 6)), [[0, 0, 0, 26, 22, 18]],
+                           [[25, 21, 17, 1, 1, 1]], [[3, 3, 0, 5, 5, 4]]])  # whole volume, one voxel, empty mask
+    want, freqs = oracle.roi_histograms(feat, np.minimum(m, 1), rois, edges)
+    got = ctx.roi_histograms(feat, m, rois, edges)
+    assert np.array_equal(got, want)
+    assert want[-1].sum() == 0 and np.isnan(freqs[-1]).all()      # 0/0 as in getFrequencies
+    planar = np.ascontiguousarray(np.moveaxis(feat, -1, 0))
+    assert np.array_equal(ctx.roi_histograms(planar, m.astype(np.uint16), rois, edges, layout=ife.PLANAR), want)
+    with pytest.raises(ife.IfeError) as ei:
+        ctx.roi_histograms(feat, m, [[20, 0, 0, 7, 5, 6]], edges)
+    assert ei.value.code == ife.E_ARG and "outside of the largest possible region" in str(ei.value)
+
+
+def test_bag_image_matches_tool_semantics(ctx, oracle, synth):
+    rng = np.random.default_rng(43)
+    shape = (24, 28, 32)
+    img = synth.volume_f32(shape, 77)
+    lab = synth.mask_ellipsoids(shape)
+    sigmas = [1.0, 2.0]
+    clamped = np.minimum(lab, 1).astype(np.uint8)
+    feats = [oracle.emphysema_features(img, clamped, s) for s in sigmas]
+    # histogram specification: equalizing edges of the whole foreground, 9 bins
+    edges = np.stack([oracle.equalized_edges(oracle.sort_f32(f[..., c][clamped != 0]), 9)
+                      for f in feats for c in range(8)])
+    rois = random_rois(rng, shape, 12, (9, 9, 7))
+    got = ctx.bag_image(img, lab, sigmas, rois, edges)
+    assert got.shape == (12, 16, 9)
+    for i, f in enumerate(feats):
+        want, _ = oracle.roi_histograms(f, clamped, rois, edges[i * 8:(i + 1) * 8])
+        assert np.array_equal(got[:, i * 8:(i + 1) * 8, :], want), i

@@ -207,3 +207,68 @@ def test_histogram_edges_tool(built, tmp_path, synth, oracle):
     # more bins than samples: the reference throws std::out_of_range; here a message and EXIT_FAILURE
     bad = run(tool, *[x if x != str(nbins) else "100000" for x in args], "-S", "10")
     assert bad.returncode == 1 and "Too many bins" in bad.stderr
+
+
+def test_makebag_usage(built):
+    h = run("MakeBag", "--help")
+    assert h.returncode == 0
+    assert all(f in h.stdout for f in ("--histogram-spec", "--outdir", "--roi-file", "--roi-file-has-header",
+                                       "--roi-mask", "--roi-mask-value", "--num-rois", "--roi-size-x", "--prefix"))
+    assert run("MakeBag", "-i", "x").returncode == 1
+
+
+@pytest.mark.gpu
+def test_makebag_tool(built, tmp_path, synth, oracle):
+    """ROI file branch against the oracle (bag rows of tools/MakeBag.cxx:405-486), then the
+    generated-ROI branch: .ROIInfo in the reader's own format, boxes inside, centred on mask."""
+    shape, scales, nbins = (24, 28, 32), [1.0, 2.0], 7
+    img = synth.volume_f32(shape, 401)
+    lab = synth.mask_ellipsoids(shape).astype(np.uint16)
+    niftiio.write(str(tmp_path / "img.nii.gz"), img)
+    niftiio.write(str(tmp_path / "lab.nii.gz"), lab)
+    clamped = np.minimum(lab, 1).astype(np.uint8)
+    feats = [oracle.emphysema_features(img, clamped, s) for s in scales]
+    edges = np.stack([oracle.equalized_edges(oracle.sort_f32(f[..., c][clamped != 0]), nbins)
+                      for f in feats for c in range(8)])
+    spec = "# Features: ...\n# Scales: 1 2\n" + "".join(",".join("%.9g" % v for v in row) + "\n" for row in edges)
+    (tmp_path / "hist.txt").write_text(spec)
+    rng = np.random.default_rng(5)
+    rois = np.stack([rng.integers(0, 32 - 9, 6), rng.integers(0, 28 - 8, 6), rng.integers(0, 24 - 7, 6)], 1)
+    (tmp_path / "rois.txt").write_text("index size\n" + "".join("[%d, %d, %d][9, 8, 7]\n" % tuple(r) for r in rois))
+    os.mkdir(str(tmp_path / "out"))
+    r = run("MakeBag", "-i", str(tmp_path / "img.nii.gz"), "-m", str(tmp_path / "lab.nii.gz"),
+            "-H", str(tmp_path / "hist.txt"), "-o", str(tmp_path / "out"), "-s", "1", "-s", "2",
+            "-r", str(tmp_path / "rois.txt"), "-p", "case1")
+    assert r.returncode == 0, r.stderr
+    assert "Got 6 rois." in r.stdout and r.stdout.count("Skipping a line") == 2
+    boxes = np.concatenate([rois, np.tile([9, 8, 7], (6, 1))], 1)
+    rows = (tmp_path / "out" / "case1.bag").read_text().splitlines()
+    assert len(rows) == 6
+    edges32 = np.array([[np.float32(float("%.9g" % v)) for v in row] for row in edges], np.float32)
+    for j, row in enumerate(rows):
+        want = []
+        for i, f in enumerate(feats):
+            _, fr = oracle.roi_histograms(f, clamped, boxes[j:j + 1], edges32[i * 8:(i + 1) * 8])
+            want += ["%g" % v for v in fr.ravel()]
+        # a region without mask voxels gives 0/0: x86 prints the default NaN as "-nan"
+        assert [t.replace("-nan", "nan") for t in row.split(",")] == want, j
+    # generated regions
+    env = dict(os.environ, IFE_SEED="11")
+    r = subprocess.run([os.path.join(BIN, "MakeBag"), "-i", str(tmp_path / "img.nii.gz"), "-m",
+                        str(tmp_path / "lab.nii.gz"), "-H", str(tmp_path / "hist.txt"), "-o", str(tmp_path / "out"),
+                        "-s", "1", "-s", "2", "-n", "5", "-x", "7", "-y", "5", "-z", "3", "-p", "gen"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    info = (tmp_path / "out" / "gen.ROIInfo").read_text().splitlines()
+    assert len(info) == 5 and len((tmp_path / "out" / "gen.bag").read_text().splitlines()) == 5
+    import re
+    for ln in info:
+        m = re.fullmatch(r"\[(\d+), (\d+), (\d+)\]\[7, 5, 3\]", ln)
+        assert m, ln
+        x, y, z = (int(v) for v in m.groups())
+        assert x + 7 <= 32 and y + 5 <= 28 and z + 3 <= 24
+        assert lab[z + 1, y + 2, x + 3] != 0          # centre = start + size/2 lies on the mask
+    # wrong number of histogram rows
+    r = run("MakeBag", "-i", str(tmp_path / "img.nii.gz"), "-m", str(tmp_path / "lab.nii.gz"),
+            "-H", str(tmp_path / "hist.txt"), "-o", str(tmp_path / "out"), "-s", "1", "-r", str(tmp_path / "rois.txt"))
+    assert r.returncode == 1 and "Number of histograms must match" in r.stderr
