@@ -62,6 +62,13 @@ class VectorIndexSelectionCastImageFilter {
     for (size_t i = 0; i < n; ++i) d[i] = (typename TImage::PixelType)s[i * nc + index_];
   }
   TImage *GetOutput() { return out_.IsNull() ? (out_ = TImage::New()).GetPointer() : out_.GetPointer(); }
+  // give the output image away (the next Update allocates a new one): for writers that
+  // outlive this filter's next execution
+  typename TImage::Pointer DetachOutput() {
+    typename TImage::Pointer p = out_;
+    out_ = typename TImage::Pointer();
+    return p;
+  }
 
  private:
   const TVectorImage *in_ = nullptr;

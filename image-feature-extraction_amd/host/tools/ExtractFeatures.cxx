@@ -1,12 +1,14 @@
 // ExtractFeatures -- multi-scale driver of the feature filter; same flags, flow and output
 // names as the reference's tools/ExtractFeatures.cxx (:26-63 flags, :126-143 naming:
 // <out>_scale_<std::to_string(scale)><FeatureName>.nii.gz).  The arithmetic runs on the
-// MI355X through libife_hip.so.
+// MI355X through libife_hip.so; the eight files of a scale are compressed and written on
+// worker threads while the device computes the next scale (ife/Host/AsyncWriter.h).
 #include <iostream>
 
 #include "tclap/CmdLine.h"
 
 #include "ife/Filters/ImageToEmphysemaFeaturesFilter.h"
+#include "ife/Host/AsyncWriter.h"
 #include "ife/Host/ImageIO.h"
 #include "ife/Host/LiteFilters.h"
 #include "ife/Util/Path.h"
@@ -59,8 +61,7 @@ int main(int argc, char *argv[]) {
   FeatureFilterType::Pointer featureFilter = FeatureFilterType::New();
   typedef itk::VectorIndexSelectionCastImageFilter<VectorImageType, ImageType> IndexSelectionType;
   IndexSelectionType::Pointer indexSelectionFilter = IndexSelectionType::New();
-  typedef itk::ImageFileWriter<ImageType> WriterType;
-  WriterType::Pointer writer = WriterType::New();
+  ife::host::AsyncWriter<ImageType> writers;
 
   std::vector<std::string> featureNames{"GaussianBlur", "GradientMagnitude", "Eigenvalue1",
                                         "Eigenvalue2",  "Eigenvalue3",       "LaplacianOfGaussian",
@@ -71,18 +72,18 @@ int main(int argc, char *argv[]) {
     featureFilter->SetInputImage(reader->GetOutput());
     featureFilter->SetInputMask(clampFilter->GetOutput());
     indexSelectionFilter->SetInput(featureFilter->GetOutput());
-    writer->SetInput(indexSelectionFilter->GetOutput());
     for (auto scale : scales) {
       featureFilter->SetSigma(scale);
       for (unsigned int i = 0; i < featureNames.size(); ++i) {
         indexSelectionFilter->SetIndex(i);
         outPath = outBasePath + "_scale_" + std::to_string(scale) + featureNames[i] + outFileType();
-        writer->SetFileName(outPath);
         featureFilter->UpdateLargestPossibleRegion();
         indexSelectionFilter->Update();
-        writer->Update();
+        // hand the selected component to the writers; the filter makes a new image next time
+        writers.Submit(indexSelectionFilter->DetachOutput(), outPath);
       }
     }
+    writers.Wait();
   } catch (itk::ExceptionObject &e) {
     std::cerr << "Failed to process." << std::endl
               << "Image: " << imagePath << std::endl
