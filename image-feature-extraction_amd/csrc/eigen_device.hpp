@@ -127,25 +127,61 @@ __device__ __forceinline__ float div_shared(float n, const SharedRecip &s) {
   return fmaf(fmaf(-s.d, q, n), s.r, q);
 }
 
-// asin(s) = s + s*z*P(z), z = s^2 <= 0.25 (degree-11 minimax fit, |err P| < 2.4e-16)
-__device__ __forceinline__ double asin_poly(double z) {
-  double p = 0.028169218060881414;
-  p = fma(p, z, -0.010749050339697808);
-  p = fma(p, z, 0.01603551434914882);
-  p = fma(p, z, 0.0078029494773533175);
-  p = fma(p, z, 0.011875494382636922);
-  p = fma(p, z, 0.013929652902326633);
-  p = fma(p, z, 0.017355259955786323);
-  p = fma(p, z, 0.02237204763174451);
-  p = fma(p, z, 0.03038194736709848);
-  p = fma(p, z, 0.044642857103423646);
-  p = fma(p, z, 0.07500000000020764);
-  p = fma(p, z, 0.1666666666666665);
+// ---- double constants of the fast solver ----------------------------------------------
+// A double operand cannot be an instruction literal, so every coefficient below costs a
+// v_mov_b64 (or two v_mov_b32) per use when the compiler has no scalar registers left for
+// it -- 51 of the feature kernel's 337 vector instructions per voxel.  The kernels that
+// are short of scalar registers therefore read the table from LDS instead (a broadcast
+// ds_read_b64 issues beside the vector unit); everything else uses the immediates.
+enum {
+  EK_AS0 = 0,    // 12 asin coefficients, highest degree first
+  EK_CS0 = 12,   // 7 cos coefficients, highest degree first
+  EK_PIO2_HI = 19, EK_PIO2_LO, EK_PI_HI, EK_PI_LO, EK_TWO_PI_3, EK_THIRD, EK_COUNT
+};
+__device__ constexpr double kEigConst[EK_COUNT] = {
+    // asin(s) = s + s*z*P(z), z = s^2 <= 0.25 (degree-11 minimax fit, |err P| < 2.4e-16)
+    0.028169218060881414, -0.010749050339697808, 0.01603551434914882, 0.0078029494773533175,
+    0.011875494382636922, 0.013929652902326633, 0.017355259955786323, 0.02237204763174451,
+    0.03038194736709848, 0.044642857103423646, 0.07500000000020764, 0.1666666666666665,
+    // cos on [-0.1, 1.1]:  1 - w/2 + w^2 C(w), w = y^2 (degree-6 fit, |err| < 4e-18)
+    4.7137756144213336e-14, -1.1469654898726794e-11, 2.0876747999120392e-09, -2.75573191859408e-07,
+    2.4801587301510604e-05, -0.001388888888888883, 0.041666666666666664,
+    1.57079632679489655800e+00, 6.12323399573676603587e-17,   // pi/2 hi, lo
+    3.14159265358979311600e+00, 1.22464679914735320717e-16,   // pi hi, lo
+    M_PI * (2.0 / 3.0),                                       // Symmetric3x3EigenvalueSolver.h:120
+    0x1.5555555555555p-2};                                    // RN(1/3)
+struct EigConstImm {
+  __device__ __forceinline__ double operator[](int i) const { return kEigConst[i]; }
+};
+struct EigConstLds {
+  typedef __attribute__((address_space(3))) const double lds_f64;
+  lds_f64 *tab;  // EK_COUNT doubles, filled by eig_const_fill before the first use
+  __device__ __forceinline__ double operator[](int i) const { return tab[i]; }
+  // The table never changes, so the compiler would lift all its loads out of the caller's
+  // loop and carry 50 registers; an address it cannot see through keeps them inside the
+  // iteration, where they are issued together ahead of the polynomial that uses them.
+  __device__ __forceinline__ static EigConstLds at(const double *shared_table) {
+    unsigned a = (unsigned)(uintptr_t)(lds_f64 *)shared_table;
+    asm volatile("" : "+v"(a));
+    return EigConstLds{(lds_f64 *)(uintptr_t)a};
+  }
+};
+// call from every thread of the workgroup, then barrier before the first solve
+__device__ __forceinline__ void eig_const_fill(double *tab) {
+  if (threadIdx.x < EK_COUNT) tab[threadIdx.x] = kEigConst[threadIdx.x];
+}
+
+template <typename KT>
+__device__ __forceinline__ double asin_poly(double z, const KT &K) {
+  double p = K[EK_AS0];
+#pragma unroll
+  for (int i = 1; i < 12; ++i) p = fma(p, z, K[EK_AS0 + i]);
   return p;
 }
 // acos on (-1, 1); the argument is a float so 1 - |r| is exact
-__device__ __forceinline__ double acos_unit(float rf) {
-  const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17;
+template <typename KT>
+__device__ __forceinline__ double acos_unit(float rf, const KT &K) {
+  const double PIO2_HI = K[EK_PIO2_HI], PIO2_LO = K[EK_PIO2_LO];
   const double r = (double)rf;
   const double a = fabs(r);
   const bool big = a > 0.5;
@@ -158,7 +194,7 @@ __device__ __forceinline__ double acos_unit(float rf) {
   h = fma(h, e, h);
   g = fma(fma(-g, g, z), h, g);
   const double s = big ? g : a;
-  const double t = fma(s * z, asin_poly(z), s);  // asin(s)
+  const double t = fma(s * z, asin_poly(z, K), s);  // asin(s)
   // |r| <= 0.5: pi/2 - sign(r) asin|r| ; r > 0.5: 2 asin(s) ; r < -0.5: pi - 2 asin(s)
   const double ts = r < 0.0 ? -t : t;
   const double small = (PIO2_HI - ts) + PIO2_LO;
@@ -166,20 +202,17 @@ __device__ __forceinline__ double acos_unit(float rf) {
   const double bigv = r < 0.0 ? (2.0 * PIO2_HI - t2) + 2.0 * PIO2_LO : t2;
   return big ? bigv : small;
 }
-// cos on [-0.1, 1.1]:  1 - w/2 + w^2 C(w), w = y^2 (degree-6 fit, |err| < 4e-18)
-__device__ __forceinline__ double cos_small(double y) {
+template <typename KT>
+__device__ __forceinline__ double cos_small(double y, const KT &K) {
   const double w = y * y;
-  double c = 4.7137756144213336e-14;
-  c = fma(c, w, -1.1469654898726794e-11);
-  c = fma(c, w, 2.0876747999120392e-09);
-  c = fma(c, w, -2.75573191859408e-07);
-  c = fma(c, w, 2.4801587301510604e-05);
-  c = fma(c, w, -0.001388888888888883);
-  c = fma(c, w, 0.041666666666666664);
+  double c = K[EK_CS0];
+#pragma unroll
+  for (int i = 1; i < 7; ++i) c = fma(c, w, K[EK_CS0 + i]);
   return fma(w * w, c, fma(-0.5, w, 1.0));
 }
-__device__ __forceinline__ double div3_f64(double x) {
-  const double y = 0x1.5555555555555p-2;  // RN(1/3)
+template <typename KT>
+__device__ __forceinline__ double div3_f64(double x, const KT &K) {
+  const double y = K[EK_THIRD];
   const double q = x * y;
   return fma(fma(-3.0, q, x), y, q);
 }
@@ -192,9 +225,9 @@ __device__ __noinline__ Eig3 eig3_sym_generic_call(float A11, float A12, float A
   return eig3_sym<0>(A11, A12, A13, A22, A23, A33);
 }
 
+template <typename KT>
 __device__ __forceinline__ Eig3 eig3_sym_fast(float A11, float A12, float A13, float A22,
-                                             float A23, float A33) {
-  const double PI_HI = 3.14159265358979311600e+00, PI_LO = 1.22464679914735320717e-16;
+                                             float A23, float A33, const KT &K) {
   float p = A12 * A12 + A13 * A13 + A23 * A23;
   const bool diag = p == 0.0f;
   const float q = div_by_3(A11 + A22 + A33);
@@ -210,15 +243,15 @@ __device__ __forceinline__ Eig3 eig3_sym_fast(float A11, float A12, float A13, f
                    B13 * B13 * B22 - B12 * B12 * B33;
   const float rr = r2 * 0.5f;
   const float twop = 2.0f * p;
-  float phi = (float)div3_f64(acos_unit(rr));
+  float phi = (float)div3_f64(acos_unit(rr, K), K);
   phi = rr >= 1.0f ? 0.0f : phi;
   phi = rr <= -1.0f ? (float)(M_PI / 3) : phi;
   const double qd = (double)q, tpd = (double)twop, phid = (double)phi;
-  float e0 = (float)(qd + tpd * cos_small(phid));
+  float e0 = (float)(qd + tpd * cos_small(phid, K));
   // cos(phi + 2pi/3) = -cos(pi - (phi + 2pi/3)); pi - arg is exact in double-double
-  const double arg = phid + M_PI * (2.0 / 3.0);
-  const double yy = (PI_HI - arg) + PI_LO;
-  float e2 = (float)(qd - tpd * cos_small(yy));
+  const double arg = phid + K[EK_TWO_PI_3];
+  const double yy = (K[EK_PI_HI] - arg) + K[EK_PI_LO];
+  float e2 = (float)(qd - tpd * cos_small(yy, K));
   float e1 = 3.0f * q - e0 - e2;
   if (fabsf(e0) < fabsf(e2)) { const float t = e0; e0 = e2; e2 = t; }
   if (fabsf(e1) < fabsf(e2)) { const float t = e1; e1 = e2; e2 = t; }
@@ -250,10 +283,10 @@ struct EigFeat {
 };
 
 // EigenvalueFeaturesFunctor.h:24-29
-template <int TRIG>
+template <int TRIG, typename KT = EigConstImm>
 __device__ __forceinline__ EigFeat eig_features(float A11, float A12, float A13, float A22,
-                                                float A23, float A33) {
-  const Eig3 ev = TRIG == 0 ? eig3_sym_fast(A11, A12, A13, A22, A23, A33)
+                                                float A23, float A33, const KT &K = KT()) {
+  const Eig3 ev = TRIG == 0 ? eig3_sym_fast(A11, A12, A13, A22, A23, A33, K)
                             : eig3_sym<TRIG>(A11, A12, A13, A22, A23, A33);
   EigFeat o;
   o.f[0] = ev.e0;

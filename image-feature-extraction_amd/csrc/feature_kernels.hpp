@@ -77,6 +77,9 @@ struct ValSmooth {
   }
   __device__ __forceinline__ float finish(const Raw &r) const {
     if (den == nullptr) return r.a;
+    // A/1 == A: a wave whose certainties are all exactly one (the interior of a mask,
+    // DESIGN.md "all-ones certainty") skips the division (scalar branch)
+    if (__builtin_amdgcn_ballot_w64(r.b != 1.0f) == 0) return r.a;
     return r.b != 0.0f ? r.a / r.b : FLT_MAX;
   }
 };
@@ -131,6 +134,9 @@ constexpr int FT_NLD = (FT_NE + FT_THREADS - 1) / FT_THREADS;  // staged element
 // Both forms are bit-identical to the generic inner products, except that the sign of
 // an exact zero is not tracked (+0/-0 compare equal and never reach a non-zero output).
 template <int MODE, bool UNIT, int TRIG, bool PLANAR, typename VAL, typename TM>
+#ifndef IFE_FT_KLDS
+#define IFE_FT_KLDS 1  // 1: solver constants from LDS, 0: immediates
+#endif
 #ifndef IFE_FT_WAVES
 #define IFE_FT_WAVES 1
 #endif
@@ -143,6 +149,10 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
   constexpr int MT_DW = FT_TY * FT_TX * (int)sizeof(TM) / 4;  // dwords per plane tile
   constexpr int MT_DWROW = FT_TX * (int)sizeof(TM) / 4;       // dwords per tile row
   __shared__ uint32_t mtile[2][MT_DW];
+  // double constants of the solver, read from LDS (eigen_device.hpp "double constants")
+  constexpr bool KLDS = TRIG == 0 && (MODE == FEAT_FEATURES8 || MODE == FEAT_EIG6) && IFE_FT_KLDS;
+  __shared__ double ktab[KLDS ? EK_COUNT : 1];
+  if (KLDS) eig_const_fill(ktab);  // the barrier of the first plane iteration covers it
   constexpr int NOUT = FeatNOut<MODE>::value;
   constexpr bool NEED_H = MODE != FEAT_GRADMAG;
   constexpr bool NEED_G = MODE == FEAT_FEATURES8 || MODE == FEAT_GRADMAG;
@@ -218,13 +228,37 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
   // The outputs of plane z are stored at the top of iteration z+1, after that iteration's
   // wait for its staged loads: the wait (vmcnt counts loads and stores in order) then never
   // sits behind stores that were issued a moment ago.
+  //
+  // Interleaved outputs: a lane's record is NOUT consecutive floats, so a store instruction
+  // of the plain form writes 16 of every 32 bytes and the two instructions of a voxel row
+  // interleave (measured: 2.7 TB/s, and no gain from a sparse mask).  The records of a wave
+  // (one tile row = 64 x-consecutive voxels = one contiguous run of memory) are therefore
+  // turned through a wave-private LDS strip so that store k of lane l carries piece
+  // k*64 + l of that run: every instruction writes one contiguous kilobyte.
+  constexpr bool XPOSE = !PLANAR && (NOUT == 8 || NOUT == 6);
+  constexpr int XW = NOUT == 8 ? 4 : 2;            // floats per store
+  constexpr int XN = XPOSE ? NOUT / XW : 1;        // stores per lane
+  __shared__ float xstrip[XPOSE ? FT_THREADS / 64 : 1][XPOSE ? 64 * NOUT : 1];
+  const int row_valid = min(FT_TX, g.nx - bx * FT_TX);  // in-bounds voxels of this wave's row
   float po[NOUT];
-  int64_t pidx = -1;
+  int64_t pidx = -1;  // XPOSE: index of the row's first voxel; else this lane's voxel
   auto flush = [&]() {
     if (pidx < 0) return;
     if constexpr (PLANAR) {
 #pragma unroll
       for (int k = 0; k < NOUT; ++k) out[(int64_t)k * g.nvox + pidx] = po[k];
+    } else if constexpr (XPOSE) {
+      float *q = out + pidx * NOUT;
+#pragma unroll
+      for (int k = 0; k < XN; ++k) {
+        const int e = (k * 64 + tx) * XW;  // first float of this lane's piece
+        if (e < row_valid * NOUT) {
+          if constexpr (XW == 4)
+            *reinterpret_cast<float4 *>(q + e) = make_float4(po[4 * k], po[4 * k + 1], po[4 * k + 2], po[4 * k + 3]);
+          else
+            *reinterpret_cast<float2 *>(q + e) = make_float2(po[2 * k], po[2 * k + 1]);
+        }
+      }
     } else if constexpr (NOUT == 8) {
       float4 *q = reinterpret_cast<float4 *>(out + pidx * 8);
       q[0] = make_float4(po[0], po[1], po[2], po[3]);
@@ -249,14 +283,16 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
       if (mine) mr = *reinterpret_cast<const uint32_t *>(mask + (int64_t)(z + 1) * g.plane + moff);
     }
     __syncthreads();
-    if (!inb) continue;
+    if (XPOSE ? (y >= g.ny || row_valid <= 0) : !inb) continue;  // XPOSE: whole waves only
 
     const int64_t idx = (int64_t)x + (int64_t)g.nx * ((int64_t)y + (int64_t)g.ny * z);
-    bool keep = true;
-    if (mvec)
-      keep = reinterpret_cast<const TM *>(mtile[z & 1])[ty * FT_TX + tx] != (TM)0;
-    else if (mask != nullptr)
-      keep = mask[idx] != (TM)0;
+    bool keep = inb;  // lanes past the row end (XPOSE) compute on clamped values, store nothing
+    if (inb) {
+      if (mvec)
+        keep = reinterpret_cast<const TM *>(mtile[z & 1])[ty * FT_TX + tx] != (TM)0;
+      else if (mask != nullptr)
+        keep = mask[idx] != (TM)0;
+    }
     float (&o)[NOUT] = po;  // results are built in the carried registers
 #pragma unroll
     for (int k = 0; k < NOUT; ++k) o[k] = 0.0f;
@@ -326,7 +362,11 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
         if constexpr (MODE == FEAT_HESSIAN6) {
           o[0] = dxx; o[1] = dxy; o[2] = dxz; o[3] = dyy; o[4] = dyz; o[5] = dzz;
         } else {
-          const EigFeat ef = eig_features<TRIG>(dxx, dxy, dxz, dyy, dyz, dzz);
+          EigFeat ef;
+          if constexpr (KLDS)
+            ef = eig_features<TRIG>(dxx, dxy, dxz, dyy, dyz, dzz, EigConstLds::at(ktab));
+          else
+            ef = eig_features<TRIG>(dxx, dxy, dxz, dyy, dyz, dzz);
           if constexpr (MODE == FEAT_FEATURES8) {
             o[0] = c; o[1] = G;
 #pragma unroll
@@ -342,7 +382,34 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
 #pragma unroll
       for (int k = 0; k < NOUT; ++k) o[k] = 0.0f;
     }
-    pidx = idx;
+    if constexpr (XPOSE) {
+      float *xs = xstrip[tid >> 6];
+      if constexpr (XW == 4) {
+        *reinterpret_cast<float4 *>(xs + tx * 8) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4 *>(xs + tx * 8 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < XN; ++k)
+          *reinterpret_cast<float2 *>(xs + tx * NOUT + 2 * k) = make_float2(o[2 * k], o[2 * k + 1]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int k = 0; k < XN; ++k) {
+        if constexpr (XW == 4) {
+          const float4 v = *reinterpret_cast<const float4 *>(xs + (k * 64 + tx) * 4);
+          o[4 * k] = v.x; o[4 * k + 1] = v.y; o[4 * k + 2] = v.z; o[4 * k + 3] = v.w;
+        } else {
+          const float2 v = *reinterpret_cast<const float2 *>(xs + (k * 64 + tx) * 2);
+          o[2 * k] = v.x; o[2 * k + 1] = v.y;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      pidx = idx - tx;  // first voxel of the row
+    } else {
+      pidx = idx;
+    }
   }
   flush();
 }
@@ -356,7 +423,7 @@ __global__ __launch_bounds__(256) void eig_batch_kernel(const float *__restrict_
   if (i >= n) return;
   const float *a = A6 + i * 6;
   if (NOUT == 3) {
-    Eig3 e = trig == 0 ? eig3_sym_fast(a[0], a[1], a[2], a[3], a[4], a[5])
+    Eig3 e = trig == 0 ? eig3_sym_fast(a[0], a[1], a[2], a[3], a[4], a[5], EigConstImm())
                        : eig3_sym<1>(a[0], a[1], a[2], a[3], a[4], a[5]);
     outv[i * 3 + 0] = e.e0; outv[i * 3 + 1] = e.e1; outv[i * 3 + 2] = e.e2;
   } else {
