@@ -39,8 +39,8 @@ for f in glob.glob(os.path.join(prof_root, "*", "*kernel_stats.csv")):
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = short(row["Name"])
-            if k not in ctr:
-                continue
+            if k not in ctr or not k.startswith("ife::"):
+                continue  # the bench's own copy-bandwidth probe is not part of the step
             fetch = ctr[k]["FETCH_SIZE"]
             write = ctr[k]["WRITE_SIZE"]
             rd = 2.0 * 1024.0 * sum(fetch) / len(fetch)
