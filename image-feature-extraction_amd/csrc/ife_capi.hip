@@ -78,7 +78,7 @@ struct ife_ctx {
   int dscale_mode = 0;
   int profile = 0;
   int zchunk = 64;
-  int iir_block = 16;
+  int iir_block = 12;  // strided axes; the x pass runs 16 unless 8 is asked for
   int iir_fma = 0;   // 1: fused multiply-add in the line recurrences (opt-in, not bit-exact)
   int iir_ckpt = 2;  // register blocks per checkpoint of the strided line kernel: 1 or 2
   // per scale slot: numerator ping/pong, denominator ping/pong (up to three scales run
@@ -272,7 +272,7 @@ IirGeom geom_for_axis(const ife_volume_desc *v, int axis) {
 size_t ck_pairs(int64_t n, int K) { return (size_t)((n + K - 1) / K); }
 
 int ensure_ck(ife_ctx *ctx, const ife_volume_desc *v, int njobs) {
-  const int K = ctx->iir_block;
+  const int K = 8;  // sized for the smallest register block any axis may run with
   size_t need_y = 0, need_x = 0;
   for (int a = 0; a < 3; ++a) {
     IirGeom g = geom_for_axis(v, a);
@@ -331,8 +331,14 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
     if (gauss_coeffs(sigma[j], sp, &jobs.j[j].c))
       return fail(ctx, IFE_E_ARG, "spacing is suspiciously small");
   }
-  const dim3 grid((unsigned)((g.nlines + 255) / 256), (unsigned)njobs, 1);
+  g.njobs = njobs;
+  g.ngroups = (int32_t)((g.nlines + 255) / 256);
+  const dim3 grid((unsigned)((g.ngroups + 7) / 8 * 8 * njobs), 1, 1);  // job-fastest, padded
   ProfScope ps(ctx, axis == 2 ? KK_IIR_Z : axis == 1 ? KK_IIR_Y : KK_IIR_X);
+#ifndef IFE_Z_BLOCK
+#define IFE_Z_BLOCK 0
+#endif
+  const int sblock = (axis == 2 && IFE_Z_BLOCK) ? IFE_Z_BLOCK : ctx->iir_block;
 #define IFE_LAUNCH_IIR(NS)                                                                      \
   do {                                                                                          \
     if (axis == 0) {                                                                            \
@@ -346,8 +352,10 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
       else                                                                                      \
         hipLaunchKernelGGL((NS::iir_strided1_kernel<16>), grid, dim3(256), 0, ctx->stream, jobs, g); \
     } else {                                                                                    \
-      if (ctx->iir_block == 8)                                                                  \
+      if (sblock == 8)                                                                          \
         hipLaunchKernelGGL((NS::iir_strided_kernel<8>), grid, dim3(256), 0, ctx->stream, jobs, g); \
+      else if (sblock == 12)                                                                    \
+        hipLaunchKernelGGL((NS::iir_strided_kernel<12>), grid, dim3(256), 0, ctx->stream, jobs, g); \
       else                                                                                      \
         hipLaunchKernelGGL((NS::iir_strided_kernel<16>), grid, dim3(256), 0, ctx->stream, jobs, g); \
     }                                                                                           \
@@ -624,7 +632,8 @@ int ife_ctx_set_option(ife_ctx *ctx, int option, int value) {
       ctx->iir_ckpt = value;
       return IFE_OK;
     case IFE_OPT_IIR_BLOCK:
-      if (value != 8 && value != 16) return fail(ctx, IFE_E_ARG, "iir block must be 8 or 16");
+      if (value != 8 && value != 12 && value != 16)
+        return fail(ctx, IFE_E_ARG, "iir block must be 8, 12 (strided axes only; x keeps 16) or 16");
       ctx->iir_block = value;
       return IFE_OK;
   }

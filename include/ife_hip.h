@@ -67,7 +67,8 @@ typedef enum {
   IFE_OPT_PROFILE = 3,
   /* planes per workgroup march of the feature kernel (default 64) */
   IFE_OPT_ZCHUNK = 4,
-  /* samples per register block of the recursive-Gaussian kernels: 8 or 16 */
+  /* samples per register block of the recursive-Gaussian kernels: 8, 12 (default: strided
+   * axes 12 -- three waves per SIMD --, x axis 16) or 16.  Never changes results. */
   IFE_OPT_IIR_BLOCK = 5,
   /* register blocks per checkpoint of the strided (z, y) line kernel: 2 (default, measured
    * faster) or 1 */
