@@ -335,10 +335,7 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
   g.ngroups = (int32_t)((g.nlines + 255) / 256);
   const dim3 grid((unsigned)((g.ngroups + 7) / 8 * 8 * njobs), 1, 1);  // job-fastest, padded
   ProfScope ps(ctx, axis == 2 ? KK_IIR_Z : axis == 1 ? KK_IIR_Y : KK_IIR_X);
-#ifndef IFE_Z_BLOCK
-#define IFE_Z_BLOCK 0
-#endif
-  const int sblock = (axis == 2 && IFE_Z_BLOCK) ? IFE_Z_BLOCK : ctx->iir_block;
+  const int sblock = ctx->iir_block;  // strided axes; the x pass keeps 16 unless 8 is asked for
 #define IFE_LAUNCH_IIR(NS)                                                                      \
   do {                                                                                          \
     if (axis == 0) {                                                                            \
