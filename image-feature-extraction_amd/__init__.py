@@ -74,6 +74,14 @@ def load_library():
         raise ImportError(
             "%s is missing: build it with `make -C %s` (hipcc --offload-arch=gfx950); "
             "there is no CPU fallback" % (LIB_PATH, os.path.dirname(LIB_PATH)))
+    # A torch wheel carries its own HIP runtime under the same SONAME as the system one this
+    # library links to, and whichever copy is loaded first serves the whole process.  Ours
+    # first leaves torch on a runtime it was not built for ("No HIP GPUs are available" at its
+    # first CUDA call), so where torch is installed it is imported before the library.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, f32p = C.c_void_p, C.c_int, C.c_int64, C.c_void_p
     vd = C.POINTER(VolumeDesc)

@@ -324,6 +324,8 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
   memset(&jobs, 0, sizeof jobs);
   for (int j = 0; j < njobs; ++j) {
     if (!in[j] || !out[j] || in[j] == out[j]) return fail(ctx, IFE_E_ARG, "bad job buffers");
+    if ((reinterpret_cast<uintptr_t>(in[j]) | reinterpret_cast<uintptr_t>(out[j])) % 4)
+      return fail(ctx, IFE_E_ARG, "field pointers must be aligned to 4 bytes");
     jobs.j[j].in = in[j];
     jobs.j[j].out = out[j];
     jobs.j[j].ck_y = (double *)ctx->ck_y[j].p;
@@ -438,6 +440,12 @@ int launch_features(ife_ctx *ctx, VAL val, const TM *mask, float *out,
   g.gz = (int)((v->nz + g.zchunk - 1) / g.zchunk);
   const int64_t nblocks = (int64_t)g.gx * g.gy * g.gz;
   if (nblocks > 0x7fffffff) return fail(ctx, IFE_E_SIZE, "volume too large for the feature kernel grid");
+  {  // vector stores: a misaligned pointer would fault on the device, so it is refused here
+    constexpr int nout = FeatNOut<MODE>::value;
+    const uintptr_t need = layout == IFE_PLANAR ? 4 : (nout == 8 ? 16 : nout == 6 ? 8 : 4);
+    if (reinterpret_cast<uintptr_t>(out) % need)
+      return fail(ctx, IFE_E_ARG, "output pointer must be aligned to %d bytes for this layout", (int)need);
+  }
   dim3 grid((unsigned)nblocks, 1, 1);
   ProfScope ps(ctx, KK_FEATURES);
   const bool unit = v->sx == 1.0 && v->sy == 1.0 && v->sz == 1.0;

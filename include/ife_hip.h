@@ -52,6 +52,9 @@ typedef enum {
 typedef enum { IFE_F32 = 0, IFE_I16 = 1, IFE_U8 = 2, IFE_U16 = 3 } ife_dtype;
 typedef enum { IFE_INTERLEAVED = 0, IFE_PLANAR = 1 } ife_layout;
 typedef enum { IFE_MEM_HOST = 0, IFE_MEM_DEVICE = 1 } ife_mem;
+/* IFE_MEM_DEVICE pointers must be aligned to their element size, interleaved 8-component
+ * outputs to 16 bytes and 6-component ones to 8 (vector stores); anything else is refused
+ * with IFE_E_ARG.  hipMalloc'ed buffers and whole voxels / planes inside them qualify. */
 
 /* Options for ife_ctx_set_option */
 typedef enum {

@@ -358,3 +358,19 @@ def test_checkpoint_stride_is_invisible(ctx, ife, oracle, synth, stride):
     finally:
         ctx.set_option(ife.OPT_IIR_CKPT, 2)
     np.testing.assert_array_equal(got, oracle.normalized_gaussian_convolution(img, cert, 2.0))
+
+
+def test_misaligned_device_pointers_are_refused(ctx, ife):
+    """Vector stores on a misaligned pointer would fault on the device; the library answers
+    IFE_E_ARG instead."""
+    import torch
+    shape = (8, 8, 8)
+    img = torch.zeros(shape, dtype=torch.float32, device="cuda")
+    buf = torch.zeros(8 * 8 * 8 * 8 + 4, dtype=torch.float32, device="cuda")
+    with pytest.raises(ife.IfeError) as ei:
+        ctx.emphysema_features_device(img.data_ptr(), ife.F32, None, ife.U8, shape, (1.0, 1.0, 1.0),
+                                      [1.0], buf.data_ptr() + 4, ife.INTERLEAVED)
+    assert ei.value.code == ife.E_ARG and "aligned" in str(ei.value)
+    ctx.emphysema_features_device(img.data_ptr(), ife.F32, None, ife.U8, shape, (1.0, 1.0, 1.0),
+                                  [1.0], buf.data_ptr() + 4, ife.PLANAR)   # 4-byte alignment suffices
+    torch.cuda.synchronize()
