@@ -33,12 +33,18 @@ enum FeatMode {
   FEAT_FEATURES8 = 0,  // S, |grad|, ev1..3, LoG, product, Frobenius (a5)
   FEAT_EIG6 = 1,       // ev1..3, LoG, product, Frobenius (a6)
   FEAT_HESSIAN6 = 2,   // xx, xy, xz, yy, yz, zz (a3)
-  FEAT_GRADMAG = 3     // |grad| (a7)
+  FEAT_GRADMAG = 3,    // |grad| (a7)
+  // the eight features of FEAT_FEATURES8, written only at sampled voxels and compacted in
+  // raster order into eight sample columns (row f1: the feature volume is never stored).
+  // The mask argument is then a code per voxel: bit 0 = sample here, bit 1 = label non-zero
+  // (features are zero where it is clear, as MaskImageFilter leaves them).
+  FEAT_SAMPLES8 = 4
 };
 
 template <int MODE>
 struct FeatNOut {
-  static constexpr int value = MODE == FEAT_FEATURES8 ? 8 : (MODE == FEAT_GRADMAG ? 1 : 6);
+  static constexpr int value =
+      (MODE == FEAT_FEATURES8 || MODE == FEAT_SAMPLES8) ? 8 : (MODE == FEAT_GRADMAG ? 1 : 6);
 };
 
 struct FeatGeom {
@@ -51,6 +57,10 @@ struct FeatGeom {
   // volume: zoff = 0, zc_hi = nz - 1 (replicate boundary at both ends).
   int zoff, zc_hi;
   int gx, gy, gz;  // tiles along x, y and z-chunks; the launch grid is 1-D (gx*gy*gz)
+  // FEAT_SAMPLES8 only: nvox is then the element stride between the eight columns;
+  // seg_base[bx + gx*(y + ny*z)] = samples in front of that 64-voxel row segment
+  const uint32_t *seg_base;
+  int64_t col_offset;
 };
 
 // Operator coefficients after FlipAxes and ScaleCoefficients (double), per axis.
@@ -162,12 +172,15 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
   constexpr int MT_DWROW = FT_TX * (int)sizeof(TM) / 4;       // dwords per tile row
   __shared__ uint32_t mtile[2][MT_DW];
   // double constants of the solver, read from LDS (eigen_device.hpp "double constants")
-  constexpr bool KLDS = TRIG == 0 && (MODE == FEAT_FEATURES8 || MODE == FEAT_EIG6) && IFE_FT_KLDS;
+  constexpr bool F8 = MODE == FEAT_FEATURES8 || MODE == FEAT_SAMPLES8;
+  constexpr bool SAMPLES = MODE == FEAT_SAMPLES8;
+  static_assert(!SAMPLES || PLANAR, "sample columns are written through the planar store");
+  constexpr bool KLDS = TRIG == 0 && (F8 || MODE == FEAT_EIG6) && IFE_FT_KLDS;
   __shared__ double ktab[KLDS ? EK_COUNT : 1];
   if (KLDS) eig_const_fill(ktab);  // the barrier of the first plane iteration covers it
   constexpr int NOUT = FeatNOut<MODE>::value;
   constexpr bool NEED_H = MODE != FEAT_GRADMAG;
-  constexpr bool NEED_G = MODE == FEAT_FEATURES8 || MODE == FEAT_GRADMAG;
+  constexpr bool NEED_G = F8 || MODE == FEAT_GRADMAG;
 
   const int tid = threadIdx.x;
   const int tx = tid & 63, ty = tid >> 6;
@@ -299,11 +312,19 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
 
     const int64_t idx = (int64_t)x + (int64_t)g.nx * ((int64_t)y + (int64_t)g.ny * z);
     bool keep = inb;  // lanes past the row end (XPOSE) compute on clamped values, store nothing
+    bool samp = false;
     if (inb) {
+      TM mval = (TM)3;
       if (mvec)
-        keep = reinterpret_cast<const TM *>(mtile[z & 1])[ty * FT_TX + tx] != (TM)0;
+        mval = reinterpret_cast<const TM *>(mtile[z & 1])[ty * FT_TX + tx];
       else if (mask != nullptr)
-        keep = mask[idx] != (TM)0;
+        mval = mask[idx];
+      if constexpr (SAMPLES) {
+        samp = ((int)mval & 1) != 0;
+        keep = ((int)mval & 3) == 3;
+      } else {
+        keep = mval != (TM)0;
+      }
     }
     float (&o)[NOUT] = po;  // results are built in the carried registers
 #pragma unroll
@@ -379,7 +400,7 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
             ef = eig_features<TRIG>(dxx, dxy, dxz, dyy, dyz, dzz, EigConstLds::at(ktab));
           else
             ef = eig_features<TRIG>(dxx, dxy, dxz, dyy, dyz, dzz);
-          if constexpr (MODE == FEAT_FEATURES8) {
+          if constexpr (F8) {
             o[0] = c; o[1] = G;
 #pragma unroll
             for (int k = 0; k < 6; ++k) o[2 + k] = ef.f[k];
@@ -419,6 +440,11 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
       }
       __builtin_amdgcn_wave_barrier();
       pidx = idx - tx;  // first voxel of the row
+    } else if constexpr (SAMPLES) {
+      const uint64_t sm = __builtin_amdgcn_ballot_w64(samp);
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
+      const int64_t seg = (int64_t)bx + (int64_t)g.gx * ((int64_t)y + (int64_t)g.ny * z);
+      pidx = samp ? g.col_offset + (int64_t)g.seg_base[seg] + rank : -1;
     } else {
       pidx = idx;
     }

@@ -426,12 +426,16 @@ int smooth_group(ife_ctx *ctx, const float *src_num, const float *src_den,
 
 template <int MODE, typename VAL, typename TM>
 int launch_features(ife_ctx *ctx, VAL val, const TM *mask, float *out,
-                    const ife_volume_desc *v, int layout, int halo_lo = 0, int halo_hi = 0) {
+                    const ife_volume_desc *v, int layout, int halo_lo = 0, int halo_hi = 0,
+                    const uint32_t *seg_base = nullptr, int64_t col_stride = 0,
+                    int64_t col_offset = 0) {
   FeatGeom g;
+  g.seg_base = seg_base;
+  g.col_offset = col_offset;
   g.nx = (int)v->nx; g.ny = (int)v->ny; g.nz = (int)v->nz;
   g.zchunk = ctx->zchunk;
   g.plane = v->nx * v->ny;
-  g.nvox = g.plane * v->nz;
+  g.nvox = MODE == FEAT_SAMPLES8 ? col_stride : g.plane * v->nz;
   g.zoff = halo_lo ? 1 : 0;
   g.zc_hi = (int)v->nz + g.zoff + (halo_hi ? 1 : 0) - 1;
   const DerivCoef dc = deriv_coeffs(v, ctx->dscale_mode);
@@ -450,14 +454,15 @@ int launch_features(ife_ctx *ctx, VAL val, const TM *mask, float *out,
   ProfScope ps(ctx, KK_FEATURES);
   const bool unit = v->sx == 1.0 && v->sy == 1.0 && v->sz == 1.0;
   const int planar = layout == IFE_PLANAR ? 1 : 0;
-  constexpr bool has_eig = MODE == FEAT_FEATURES8 || MODE == FEAT_EIG6;
+  constexpr bool has_eig = MODE == FEAT_FEATURES8 || MODE == FEAT_EIG6 || MODE == FEAT_SAMPLES8;
 #define IFE_LAUNCH_FEAT2(UNIT_, TRIG_, PL_)                                                    \
   hipLaunchKernelGGL((features_kernel<MODE, UNIT_, TRIG_, PL_, VAL, TM>), grid,                 \
                      dim3(FT_THREADS), 0, ctx->stream, val, mask, out, g, dc)
-#define IFE_LAUNCH_FEAT(UNIT_, TRIG_)            \
-  do {                                           \
-    if (planar) IFE_LAUNCH_FEAT2(UNIT_, TRIG_, true); \
-    else IFE_LAUNCH_FEAT2(UNIT_, TRIG_, false);  \
+#define IFE_LAUNCH_FEAT(UNIT_, TRIG_)                                                  \
+  do {                                                                                 \
+    if constexpr (MODE == FEAT_SAMPLES8) IFE_LAUNCH_FEAT2(UNIT_, TRIG_, true);         \
+    else if (planar) IFE_LAUNCH_FEAT2(UNIT_, TRIG_, true);                             \
+    else IFE_LAUNCH_FEAT2(UNIT_, TRIG_, false);                                        \
   } while (0)
   if (has_eig && ctx->trig_mode == 1) {
     if constexpr (has_eig) {
@@ -525,9 +530,19 @@ int bind(ife_ctx *ctx) {
 
 }  // namespace
 
+// Row f1: instead of a feature volume per scale, the features of the sampled voxels go
+// straight into eight sample columns per scale (stats_capi.inc).
+struct SampleSink {
+  const uint8_t *code;      // per voxel: bit 0 = sample here, bit 1 = label non-zero
+  const uint32_t *seg_base; // exclusive scan of the per-row-segment sample counts
+  float *columns;           // column (scale*8 + k) at columns + (scale*8 + k) * stride
+  int64_t stride, offset;   // elements between columns, samples already in them
+};
+
 template <typename TI, typename TM>
 static int emphysema_typed(ife_ctx *ctx, const TI *img, const TM *msk, const ife_volume_desc *vol,
-                           const float *sigmas, int n_sigmas, float *dout, int layout) {
+                           const float *sigmas, int n_sigmas, float *dout, int layout,
+                           const SampleSink *sink = nullptr) {
   const size_t n = (size_t)(vol->nx * vol->ny * vol->nz);
   float *tc = (float *)ctx->pre[0].p, *cf = (float *)ctx->pre[1].p;
   // Cast + Multiply once for all scales (the reference redoes them per scale, a9).
@@ -546,11 +561,16 @@ static int emphysema_typed(ife_ctx *ctx, const TI *img, const TM *msk, const ife
     double sg[IFE_MAX_SLOTS];
     for (int k = 0; k < ns; ++k) sg[k] = (double)sigmas[s0 + k];
     int rc = smooth_group(ctx, src_num, msk ? cf : nullptr, vol, sg, ns);
-    for (int k = 0; k < ns && !rc; ++k)
-      rc = launch_features<FEAT_FEATURES8>(
-          ctx, ValSmooth{(const float *)ctx->fld[k][0].p,
-                         msk ? (const float *)ctx->fld[k][2].p : nullptr},
-          msk, dout + (size_t)(s0 + k) * n * IFE_NUM_FEATURES, vol, layout);
+    for (int k = 0; k < ns && !rc; ++k) {
+      const ValSmooth vs{(const float *)ctx->fld[k][0].p, msk ? (const float *)ctx->fld[k][2].p : nullptr};
+      if (sink)
+        rc = launch_features<FEAT_SAMPLES8>(ctx, vs, sink->code,
+                                            sink->columns + (size_t)(s0 + k) * IFE_NUM_FEATURES * sink->stride,
+                                            vol, IFE_PLANAR, 0, 0, sink->seg_base, sink->stride, sink->offset);
+      else
+        rc = launch_features<FEAT_FEATURES8>(ctx, vs, msk, dout + (size_t)(s0 + k) * n * IFE_NUM_FEATURES, vol,
+                                             layout);
+    }
     if (rc) return rc;
   }
   return IFE_OK;

@@ -367,6 +367,66 @@ __global__ __launch_bounds__(256) void gather_indexed_kernel(const float *__rest
   }
 }
 
+// Fused sampling (FEAT_SAMPLES8): per voxel a code -- bit 0 the label is a foreground value
+// (the voxel is sampled, tool :224-232), bit 1 the label is non-zero (its features are not
+// masked to zero) -- and per 64-voxel row segment the number of sampled voxels.
+// One wave per row segment s = bx + gx*row (x in [64 bx, min(nx, 64 bx + 64)) of row (y, z)):
+// writes the codes and the segment's sample count.
+template <typename TM>
+__global__ __launch_bounds__(256) void sample_code_kernel(const TM *__restrict__ labels,
+                                                          uint8_t *__restrict__ code,
+                                                          uint32_t *__restrict__ counts, int nx,
+                                                          int gx, int64_t nseg, GatherArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t s = wave0; s < nseg; s += nwaves) {
+    const int64_t row = s / gx;
+    const int x = (int)(s % gx) * 64 + lane;
+    bool on = false;
+    if (x < nx) {
+      const int64_t i = row * nx + x;
+      on = is_foreground(labels, i, a);
+      code[i] = (uint8_t)((on ? 1 : 0) | (labels[i] != 0 ? 2 : 0));
+    }
+    const uint64_t m = __builtin_amdgcn_ballot_w64(on);
+    if (lane == 0) counts[s] = (uint32_t)__popcll(m);
+  }
+}
+
+// Exclusive scan of n counts in place, three launches: sums of chunks of SCAN_CHUNK entries,
+// scan_chunks_kernel over those sums (total in total[0]), then the scan inside every chunk.
+constexpr int SCAN_CHUNK = 4096;  // 256 threads x 16 entries
+__global__ __launch_bounds__(SORT_THREADS) void chunk_sum_kernel(const uint32_t *__restrict__ v,
+                                                                int64_t n,
+                                                                uint32_t *__restrict__ sums) {
+  __shared__ uint32_t tmp[SORT_WAVES];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + threadIdx.x * 16;
+  uint32_t t = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t += base + k < n ? v[base + k] : 0u;
+  uint32_t all = 0;
+  (void)block_excl_scan_256(t, tmp, &all);
+  if (threadIdx.x == 0) sums[blockIdx.x] = all;
+}
+__global__ __launch_bounds__(SORT_THREADS) void chunk_scan_kernel(uint32_t *__restrict__ v, int64_t n,
+                                                                 const uint32_t *__restrict__ bases) {
+  __shared__ uint32_t tmp[SORT_WAVES];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + threadIdx.x * 16;
+  uint32_t e[16], t = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    e[k] = base + k < n ? v[base + k] : 0u;
+    t += e[k];
+  }
+  uint32_t run = bases[blockIdx.x] + block_excl_scan_256(t, tmp, nullptr);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (base + k < n) v[base + k] = run;
+    run += e[k];
+  }
+}
+
 // ClampImageFilter bounds (0, 1) of the tool (:147-152): labels -> {0, 1}
 template <typename TM>
 __global__ __launch_bounds__(256) void clamp01_kernel(const TM *__restrict__ in,

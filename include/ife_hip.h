@@ -292,8 +292,9 @@ int ife_samples_add_features(ife_ctx *ctx, ife_samples *s, int first_column,
                              int mem);
 
 /* One image of the tool's loop (:176-265): the labels are clamped to {0,1} for the filter
- * (ClampImageFilter, :147-152), a5 runs at every scale with its output left in HBM, and
- * the samples of scale i go to columns [8i, 8i+8).  The samples object must have
+ * (ClampImageFilter, :147-152), a5 runs at every scale, and the samples of scale i go to
+ * columns [8i, 8i+8) -- in the all-foreground branch straight from the feature kernel (no
+ * feature volume is stored), in the sampled branch from a feature volume left in HBM.  The samples object must have
  * 8*n_sigmas columns.  indices, when given, holds n_sigmas * n_indices_per_scale voxel
  * indices, scale-major. */
 int ife_samples_add_image(ife_ctx *ctx, ife_samples *s, const void *image, int image_dtype,
