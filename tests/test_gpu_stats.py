@@ -255,3 +255,30 @@ def test_bag_image_matches_tool_semantics(ctx, oracle, synth):
     for i, f in enumerate(feats):
         want, _ = oracle.roi_histograms(f, clamped, rois, edges[i * 8:(i + 1) * 8])
         assert np.array_equal(got[:, i * 8:(i + 1) * 8, :], want), i
+
+
+def test_samples_add_image_u16_labels_and_spacing(ctx, oracle, synth):
+    """Fused sampling with uint16 labels, anisotropic spacing (the generic stencil path), a
+    ragged width (the last row segment is partial) and a label set that includes 0."""
+    shape, spacing, sigmas = (12, 18, 70), (0.7, 0.9, 1.6), [1.5]
+    img = synth.volume_f32(shape, 55)
+    lab = labels(shape, 56).astype(np.uint16) * 300            # labels 0, 300, 600
+    clamped = np.minimum(lab, 1).astype(np.uint8)
+    f = oracle.emphysema_features(img, clamped, sigmas[0], spacing)
+    for fg in [(600,), (0, 300)]:
+        s = ctx.samples(8)
+        s.add_image(img, lab, sigmas, foreground=fg, spacing=spacing)
+        sel = np.isin(lab, fg)
+        assert s.count(0) == int(sel.sum())
+        for c in range(8):
+            want = f[..., c][sel]                                 # raster order
+            got = s.column(c)
+            if c < 2:
+                assert np.array_equal(got, want), (fg, c)
+            else:                                                 # eigen features: last-bit freedom only
+                lam = np.maximum(np.abs(f[..., 2][sel]).astype(np.float64), 1e-30) ** (3 if c == 6 else 1)
+                assert (np.abs(got.astype(np.float64) - want) / lam).max() <= 3e-6, (fg, c)
+        if 0 in fg:                                               # label 0 is sampled: features are zero there
+            zero = (lab == 0)[sel]
+            assert np.all(s.column(3)[zero] == 0)
+        s.close()
