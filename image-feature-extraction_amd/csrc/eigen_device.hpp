@@ -220,12 +220,18 @@ __device__ __forceinline__ double div3_f64(double x, const KT &K) {
 // Out-of-line copy of the generic solver for the rare out-of-range fallback, so that its
 // register needs (the library cos with large-argument reduction) do not set the
 // kernel's allocation.
+template <int TRIG>
 __device__ __noinline__ Eig3 eig3_sym_generic_call(float A11, float A12, float A13, float A22,
                                                    float A23, float A33) {
-  return eig3_sym<0>(A11, A12, A13, A22, A23, A33);
+  return eig3_sym<TRIG>(A11, A12, A13, A22, A23, A33);
 }
 
-template <typename KT>
+// TRIG = 1 (float overloads of acos / cos, the <math.h> context) shares everything with
+// TRIG = 0 but the places where a value is rounded to float: acosf(r) and cosf(phi) are
+// taken as the correctly rounded floats of the double polynomials (the host libm is within
+// one ulp of that), phi = acosf(r) / 3.0f and e0 = q + 2p cosf(phi) are float operations;
+// e2 keeps the double argument and the double cos in both contexts (:120).
+template <int TRIG = 0, typename KT>
 __device__ __forceinline__ Eig3 eig3_sym_fast(float A11, float A12, float A13, float A22,
                                              float A23, float A33, const KT &K) {
   float p = A12 * A12 + A13 * A13 + A23 * A23;
@@ -243,11 +249,11 @@ __device__ __forceinline__ Eig3 eig3_sym_fast(float A11, float A12, float A13, f
                    B13 * B13 * B22 - B12 * B12 * B33;
   const float rr = r2 * 0.5f;
   const float twop = 2.0f * p;
-  float phi = (float)div3_f64(acos_unit(rr, K), K);
+  float phi = TRIG == 0 ? (float)div3_f64(acos_unit(rr, K), K) : div_by_3((float)acos_unit(rr, K));
   phi = rr >= 1.0f ? 0.0f : phi;
   phi = rr <= -1.0f ? (float)(M_PI / 3) : phi;
   const double qd = (double)q, tpd = (double)twop, phid = (double)phi;
-  float e0 = (float)(qd + tpd * cos_small(phid, K));
+  float e0 = TRIG == 0 ? (float)(qd + tpd * cos_small(phid, K)) : q + twop * (float)cos_small(phid, K);
   // cos(phi + 2pi/3) = -cos(pi - (phi + 2pi/3)); pi - arg is exact in double-double
   const double arg = phid + K[EK_TWO_PI_3];
   const double yy = (K[EK_PI_HI] - arg) + K[EK_PI_LO];
@@ -270,7 +276,7 @@ __device__ __forceinline__ Eig3 eig3_sym_fast(float A11, float A12, float A13, f
     r.e2 = diag ? d2 : r.e2;
   }
   if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {
-    const Eig3 g = eig3_sym_generic_call(A11, A12, A13, A22, A23, A33);
+    const Eig3 g = eig3_sym_generic_call<TRIG>(A11, A12, A13, A22, A23, A33);
     r.e0 = unsafe ? g.e0 : r.e0;
     r.e1 = unsafe ? g.e1 : r.e1;
     r.e2 = unsafe ? g.e2 : r.e2;
@@ -286,8 +292,7 @@ struct EigFeat {
 template <int TRIG, typename KT = EigConstImm>
 __device__ __forceinline__ EigFeat eig_features(float A11, float A12, float A13, float A22,
                                                 float A23, float A33, const KT &K = KT()) {
-  const Eig3 ev = TRIG == 0 ? eig3_sym_fast(A11, A12, A13, A22, A23, A33, K)
-                            : eig3_sym<TRIG>(A11, A12, A13, A22, A23, A33);
+  const Eig3 ev = eig3_sym_fast<TRIG>(A11, A12, A13, A22, A23, A33, K);
   EigFeat o;
   o.f[0] = ev.e0;
   o.f[1] = ev.e1;
