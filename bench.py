@@ -47,7 +47,9 @@ def parse():
     ap.add_argument("--layout", choices=["interleaved", "planar"], default="interleaved")
     ap.add_argument("--spacing", type=float, nargs=3, default=[1.0, 1.0, 1.0], metavar=("SX", "SY", "SZ"))
     ap.add_argument("--i16", action="store_true", help="int16 CT-like input (BASELINE configs[4])")
-    ap.add_argument("--trig", type=int, default=0)
+    ap.add_argument("--trig", type=int, default=2,
+                    help="IFE_OPT_TRIG_MODE: 2 (library default) float acos/cos inside the 1e-5 "
+                         "bar; 0 double evaluation, bit-faithful to the oracle")
     ap.add_argument("--iir-block", type=int, default=None)
     ap.add_argument("--iir-ckpt", type=int, default=None)
     ap.add_argument("--iir-fma", action="store_true", help="opt-in fused recurrences (not bit-exact)")
@@ -196,7 +198,7 @@ def main():
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
     default_cfg = (world == 1 and [nz, ny, nx] == [512, 512, 512] and sigmas == [1.0, 2.0, 4.0]
-                   and args.mask == "ones" and args.layout == "interleaved" and args.trig == 0
+                   and args.mask == "ones" and args.layout == "interleaved" and args.trig == 2
                    and not args.i16 and list(args.spacing) == [1.0, 1.0, 1.0])
     if default_cfg and os.path.exists(tpath):
         traffic = json.load(open(tpath)).get("traffic_bytes_per_step")

@@ -226,6 +226,44 @@ __device__ __noinline__ Eig3 eig3_sym_generic_call(float A11, float A12, float A
   return eig3_sym<TRIG>(A11, A12, A13, A22, A23, A33);
 }
 
+// ---- TRIG = 2: float trigonometry inside north_star's 1e-5 bar ---------------------------
+// q, p, B and r stay the bit-identical float values of the reference; only acos(r)/3 and
+// the two cosines are evaluated with short float polynomials (|error| of each below 2e-7),
+// so an eigenvalue moves by at most a few 1e-7 * 2p <= 1e-6 |lambda_1| (|lambda_1| >= p for
+// every symmetric matrix).  That is the spread the reference itself has between its two
+// include contexts (double functions vs float overloads), and 40 float operations instead
+// of ~200 double ones.  Fits: scripts/experiments/fit_trig.py (float section).
+__device__ __forceinline__ float acos_third_f32(float r) {
+  const float a = fabsf(r);
+  const bool big = a > 0.5f;
+  const float z = big ? (1.0f - a) * 0.5f : a * a;  // 1 - a is exact for a in [0.5, 1]
+  const float s = big ? __builtin_amdgcn_sqrtf(z) : a;
+  // asin(s) = s + s z P(z), z = s^2 <= 0.25, |err| < 3e-9
+  float p = 0x1.13fed4p-5f;
+  p = fmaf(p, z, 0x1.18f91ep-6f);
+  p = fmaf(p, z, 0x1.fd8da2p-6f);
+  p = fmaf(p, z, 0x1.6d5bbap-5f);
+  p = fmaf(p, z, 0x1.333430p-4f);
+  p = fmaf(p, z, 0x1.555554p-3f);
+  const float t = fmaf(s * z, p, s);
+  // |r| <= 0.5: pi/2 - sign(r) asin|r| ; r > 0.5: 2 asin(s) ; r < -0.5: pi - 2 asin(s); all / 3
+  const float third = 0x1.555556p-2f;
+  const float ts = r < 0.0f ? -t : t;
+  const float small = fmaf(-third, ts, 0x1.0c1524p-1f);                      // pi/6 - ts/3
+  const float t23 = t * 0x1.555556p-1f;                                      // 2t/3
+  const float bigv = r < 0.0f ? 0x1.0c1524p+0f - t23 : t23;                  // pi/3 - 2t/3
+  return big ? bigv : small;
+}
+// cos on [-0.01, 1.06]: 1 - w/2 + w^2 C(w), w = y^2, |err| < 2e-9 before rounding
+__device__ __forceinline__ float cos_small_f32(float y) {
+  const float w = y * y;
+  float c = -0x1.22df14p-22f;
+  c = fmaf(c, w, 0x1.a00bdap-16f);
+  c = fmaf(c, w, -0x1.6c16b4p-10f);
+  c = fmaf(c, w, 0x1.555556p-5f);
+  return fmaf(w * w, c, fmaf(-0.5f, w, 1.0f));
+}
+
 // TRIG = 1 (float overloads of acos / cos, the <math.h> context) shares everything with
 // TRIG = 0 but the places where a value is rounded to float: acosf(r) and cosf(phi) are
 // taken as the correctly rounded floats of the double polynomials (the host libm is within
@@ -249,15 +287,25 @@ __device__ __forceinline__ Eig3 eig3_sym_fast(float A11, float A12, float A13, f
                    B13 * B13 * B22 - B12 * B12 * B33;
   const float rr = r2 * 0.5f;
   const float twop = 2.0f * p;
-  float phi = TRIG == 0 ? (float)div3_f64(acos_unit(rr, K), K) : div_by_3((float)acos_unit(rr, K));
-  phi = rr >= 1.0f ? 0.0f : phi;
-  phi = rr <= -1.0f ? (float)(M_PI / 3) : phi;
-  const double qd = (double)q, tpd = (double)twop, phid = (double)phi;
-  float e0 = TRIG == 0 ? (float)(qd + tpd * cos_small(phid, K)) : q + twop * (float)cos_small(phid, K);
-  // cos(phi + 2pi/3) = -cos(pi - (phi + 2pi/3)); pi - arg is exact in double-double
-  const double arg = phid + K[EK_TWO_PI_3];
-  const double yy = (K[EK_PI_HI] - arg) + K[EK_PI_LO];
-  float e2 = (float)(qd - tpd * cos_small(yy, K));
+  float phi, e0, e2;
+  if constexpr (TRIG == 2) {
+    phi = acos_third_f32(rr);
+    phi = rr >= 1.0f ? 0.0f : phi;
+    phi = rr <= -1.0f ? (float)(M_PI / 3) : phi;
+    e0 = fmaf(twop, cos_small_f32(phi), q);
+    // cos(phi + 2pi/3) = -cos(pi/3 - phi), and pi/3 - phi lies in [0, pi/3] again
+    e2 = fmaf(-twop, cos_small_f32((float)(M_PI / 3) - phi), q);
+  } else {
+    phi = TRIG == 0 ? (float)div3_f64(acos_unit(rr, K), K) : div_by_3((float)acos_unit(rr, K));
+    phi = rr >= 1.0f ? 0.0f : phi;
+    phi = rr <= -1.0f ? (float)(M_PI / 3) : phi;
+    const double qd = (double)q, tpd = (double)twop, phid = (double)phi;
+    e0 = TRIG == 0 ? (float)(qd + tpd * cos_small(phid, K)) : q + twop * (float)cos_small(phid, K);
+    // cos(phi + 2pi/3) = -cos(pi - (phi + 2pi/3)); pi - arg is exact in double-double
+    const double arg = phid + K[EK_TWO_PI_3];
+    const double yy = (K[EK_PI_HI] - arg) + K[EK_PI_LO];
+    e2 = (float)(qd - tpd * cos_small(yy, K));
+  }
   float e1 = 3.0f * q - e0 - e2;
   if (fabsf(e0) < fabsf(e2)) { const float t = e0; e0 = e2; e2 = t; }
   if (fabsf(e1) < fabsf(e2)) { const float t = e1; e1 = e2; e2 = t; }
@@ -276,7 +324,7 @@ __device__ __forceinline__ Eig3 eig3_sym_fast(float A11, float A12, float A13, f
     r.e2 = diag ? d2 : r.e2;
   }
   if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {
-    const Eig3 g = eig3_sym_generic_call<TRIG>(A11, A12, A13, A22, A23, A33);
+    const Eig3 g = eig3_sym_generic_call<(TRIG == 2 ? 0 : TRIG)>(A11, A12, A13, A22, A23, A33);
     r.e0 = unsafe ? g.e0 : r.e0;
     r.e1 = unsafe ? g.e1 : r.e1;
     r.e2 = unsafe ? g.e2 : r.e2;

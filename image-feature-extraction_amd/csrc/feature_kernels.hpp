@@ -175,7 +175,7 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
   constexpr bool F8 = MODE == FEAT_FEATURES8 || MODE == FEAT_SAMPLES8;
   constexpr bool SAMPLES = MODE == FEAT_SAMPLES8;
   static_assert(!SAMPLES || PLANAR, "sample columns are written through the planar store");
-  constexpr bool KLDS = (F8 || MODE == FEAT_EIG6) && IFE_FT_KLDS;
+  constexpr bool KLDS = (F8 || MODE == FEAT_EIG6) && IFE_FT_KLDS && TRIG != 2;
   __shared__ double ktab[KLDS ? EK_COUNT : 1];
   if (KLDS) eig_const_fill(ktab);  // the barrier of the first plane iteration covers it
   constexpr int NOUT = FeatNOut<MODE>::value;
@@ -461,12 +461,14 @@ __global__ __launch_bounds__(256) void eig_batch_kernel(const float *__restrict_
   if (i >= n) return;
   const float *a = A6 + i * 6;
   if (NOUT == 3) {
-    Eig3 e = trig == 0 ? eig3_sym_fast<0>(a[0], a[1], a[2], a[3], a[4], a[5], EigConstImm())
-                       : eig3_sym_fast<1>(a[0], a[1], a[2], a[3], a[4], a[5], EigConstImm());
+    Eig3 e = trig == 0   ? eig3_sym_fast<0>(a[0], a[1], a[2], a[3], a[4], a[5], EigConstImm())
+             : trig == 1 ? eig3_sym_fast<1>(a[0], a[1], a[2], a[3], a[4], a[5], EigConstImm())
+                         : eig3_sym_fast<2>(a[0], a[1], a[2], a[3], a[4], a[5], EigConstImm());
     outv[i * 3 + 0] = e.e0; outv[i * 3 + 1] = e.e1; outv[i * 3 + 2] = e.e2;
   } else {
-    EigFeat f = trig == 0 ? eig_features<0>(a[0], a[1], a[2], a[3], a[4], a[5])
-                          : eig_features<1>(a[0], a[1], a[2], a[3], a[4], a[5]);
+    EigFeat f = trig == 0   ? eig_features<0>(a[0], a[1], a[2], a[3], a[4], a[5])
+                : trig == 1 ? eig_features<1>(a[0], a[1], a[2], a[3], a[4], a[5])
+                            : eig_features<2>(a[0], a[1], a[2], a[3], a[4], a[5]);
 #pragma unroll
     for (int k = 0; k < 6; ++k) outv[i * 6 + k] = f.f[k];
   }

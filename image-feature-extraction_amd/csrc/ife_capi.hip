@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -74,7 +75,7 @@ struct ife_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
-  int trig_mode = 0;
+  int trig_mode = 2;  // IFE_OPT_TRIG_MODE: float trigonometry inside the 1e-5 bar (ife_hip.h)
   int dscale_mode = 0;
   int profile = 0;
   int zchunk = 64;
@@ -469,6 +470,11 @@ int launch_features(ife_ctx *ctx, VAL val, const TM *mask, float *out,
       if (unit) IFE_LAUNCH_FEAT(true, 1);
       else IFE_LAUNCH_FEAT(false, 1);
     }
+  } else if (has_eig && ctx->trig_mode == 2) {
+    if constexpr (has_eig) {
+      if (unit) IFE_LAUNCH_FEAT(true, 2);
+      else IFE_LAUNCH_FEAT(false, 2);
+    }
   } else {
     if (unit) IFE_LAUNCH_FEAT(true, 0);
     else IFE_LAUNCH_FEAT(false, 0);
@@ -600,6 +606,10 @@ int ife_ctx_create(int device, ife_ctx **out) {
   ife_ctx *c = new (std::nothrow) ife_ctx();
   if (!c) return fail(nullptr, IFE_E_NOMEM, "host allocation failed");
   c->device = device;
+  // IFE_TRIG_MODE in the environment sets the initial IFE_OPT_TRIG_MODE, for callers that
+  // cannot reach ife_ctx_set_option (the drop-in tools); set_option still overrides it.
+  if (const char *e = getenv("IFE_TRIG_MODE"))
+    if ((e[0] == '0' || e[0] == '1' || e[0] == '2') && e[1] == 0) c->trig_mode = e[0] - '0';
   *out = c;
   return IFE_OK;
 }
@@ -635,7 +645,7 @@ int ife_ctx_set_option(ife_ctx *ctx, int option, int value) {
   if (!ctx) return IFE_E_ARG;
   switch (option) {
     case IFE_OPT_TRIG_MODE:
-      if (value != 0 && value != 1) return fail(ctx, IFE_E_ARG, "trig mode must be 0 or 1");
+      if (value < 0 || value > 2) return fail(ctx, IFE_E_ARG, "trig mode must be 0, 1 or 2");
       ctx->trig_mode = value;
       return IFE_OK;
     case IFE_OPT_DSCALE_MODE:

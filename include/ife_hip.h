@@ -58,9 +58,16 @@ typedef enum { IFE_MEM_HOST = 0, IFE_MEM_DEVICE = 1 } ife_mem;
 
 /* Options for ife_ctx_set_option */
 typedef enum {
-  /* 0 (default): sqrt/acos/cos of the solver evaluated in double, the binding the
-   * reference gets when only <cmath> is visible; 1: float overloads (<math.h>
-   * visible).  Symmetric3x3EigenvalueSolver.h:88,115,119-120. */
+  /* How the solver's unqualified sqrt/acos/cos (Symmetric3x3EigenvalueSolver.h:88,115,
+   * 119-120) are evaluated.  0: in double, the binding the reference gets when only <cmath>
+   * is visible (bit-identical to a libm build except at about one voxel in 10^8);
+   * 1: float overloads (<math.h> visible), correctly rounded;
+   * 2 (default): q, p, B and r as in 0/1, acos and cos by float polynomials: eigenvalues
+   * within 1e-6 |lambda_1| of mode 0 (measured maximum in DESIGN.md; the contract of this
+   * library is 1e-5), the spread the reference itself has between contexts 0 and 1, at a
+   * fifth of the instructions.  Two eigenvalues whose magnitudes tie within that error may
+   * come out in the other order.  The environment variable IFE_TRIG_MODE=0|1|2 sets the
+   * initial value at ife_ctx_create (for the tools, which have no flag for it). */
   IFE_OPT_TRIG_MODE = 1,
   /* 0 (default): DerivativeImageFilter scales by 1/spacing once whatever the order
    * (upstream ITK behaviour); 1: 1/spacing^order.  Same for unit spacing. */
