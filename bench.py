@@ -32,7 +32,15 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_VOXEL_SCALE = 37  # 4 (image) + 1 (mask) + 8*4 (out)
 # compulsory bytes per voxel of ONE field pass / feature launch of each kernel kind
 # (DESIGN.md "Kernels"): a line-kernel launch covers several (scale, field) jobs
-KERNEL_ALG_BYTES = {"iir_z": 8.0, "iir_x": 8.0, "iir_y": 8.0, "features": 41.0, "prep": 13.0}
+KERNEL_ALG_BYTES = {"iir_z": 8.0, "iir_x": 8.0, "iir_y": 8.0, "features": 41.0, "prep": 13.0,
+                    "zslab_sweep": 4.0, "zslab_combine": 8.0}
+# Second roofline (DESIGN.md "Where the time goes"): vector instructions a wave issues per
+# 64 samples of one field pass / per 64 voxels of a feature launch, from the committed PMC
+# pass (profiles/r02_pmc_summary.txt: SQ_INSTS_VALU / waves' samples).  On CDNA4 a double
+# add / multiply occupies its SIMD for 4 cycles per wave, so
+#   issue_floor_ms = instructions x 4 / (256 CUs x 4 SIMDs x sustained clock).
+VALU_PER_WAVE64 = {"iir_z": 57.0, "iir_x": 56.2, "iir_y": 57.0, "features": 262.0}
+SIMDS, SUSTAINED_GHZ = 1024, 2.03  # GRBM_GUI_ACTIVE / 8 / duration under this load
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -58,6 +66,8 @@ def parse():
     ap.add_argument("--force-slab", action="store_true",
                     help="run the Z-slab engine (RCCL exchanges) even with one rank")
     ap.add_argument("--cpu-sample", type=int, default=512, help="edge of the CPU baseline cube")
+    ap.add_argument("--line-groups", type=int, default=None,
+                    help="N>1: items per scale on the boundary-state chains (slab.py)")
     return ap.parse_args()
 
 
@@ -149,8 +159,9 @@ def main():
 
     for _ in range(args.warmup):
         runner.step()
-    runner.ctx.set_option(pkg.OPT_PROFILE, 1)
-    runner.ctx.reset_kernel_times()
+    for c in runner.contexts():
+        c.set_option(pkg.OPT_PROFILE, 1)
+        c.reset_kernel_times()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -159,8 +170,12 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    ktimes = runner.ctx.kernel_times()
-    runner.ctx.set_option(pkg.OPT_PROFILE, 0)
+    ktimes = {}
+    for c in runner.contexts():
+        for name, (n, ms) in c.kernel_times().items():
+            n0, ms0 = ktimes.get(name, (0, 0.0))
+            ktimes[name] = (n0 + n, ms0 + ms)
+        c.set_option(pkg.OPT_PROFILE, 0)
     copy_gbs = measured_copy_gbs(torch, dev) if rank == 0 else None
 
     if use_dist:
@@ -189,6 +204,11 @@ def main():
             e["units_per_step"] = units
             e["achieved_GBs"] = round(gbs, 1)
             e["frac"] = round(gbs / HBM_PEAK_GBS, 4)
+        if name in VALU_PER_WAVE64:
+            units = len(sigmas) if name == "features" else len(sigmas) * nfields
+            insts = VALU_PER_WAVE64[name] * units * (nvox / world) / 64.0
+            e["issue_floor_ms"] = round(insts * 4.0 / (SIMDS * SUSTAINED_GHZ * 1e9) * 1e3
+                                        / (n / args.steps), 4)  # per launch, like avg_ms
         kern[name] = e
     alg_bytes_step_rank = ALG_BYTES_PER_VOXEL_SCALE * (nvox / world) * len(sigmas)
     achieved = alg_bytes_step_rank / (dev_ms_step * 1e-3) / 1e9 if dev_ms_step > 0 else 0.0
@@ -196,7 +216,7 @@ def main():
     # HBM bytes per step from the committed PMC passes (profiles/, same default workload);
     # PMC counters cannot be collected from inside this process
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
     default_cfg = (world == 1 and [nz, ny, nx] == [512, 512, 512] and sigmas == [1.0, 2.0, 4.0]
                    and args.mask == "ones" and args.layout == "interleaved" and args.trig == 2
                    and not args.i16 and list(args.spacing) == [1.0, 1.0, 1.0])
@@ -206,7 +226,7 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_step": int(alg_bytes_step_rank),
                 "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
-                "traffic_source": "profiles/r01_traffic.json (rocprofv3 PMC, bytes per step)"
+                "traffic_source": "profiles/r02_traffic.json (rocprofv3 PMC, bytes per step)"
                 if traffic else None,
                 "scope": "all kernels of one step (sum of hipEvent durations %.3f ms); "
                          "algorithmic bytes = 37 B x voxels x scales" % dev_ms_step,
@@ -218,14 +238,21 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t_step * 1e3, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32 storage / f64 line recurrences", "data": "synthetic",
-        "config": {"workload": "%dx%dx%d float32 volume, sigma=%s, 8 features/voxel/scale "
+        # described from what the runner actually built
+        "config": {"workload": "%dx%dx%d %s volume, sigma=%s, 8 features/voxel/scale "
                                "(ImageToEmphysemaFeaturesFilter), uint8 mask=%s, %s output, "
-                               "%s%s" % (nx, ny, nz, sigmas, args.mask, args.layout,
-                                         "1 GPU" if world == 1 else "%d Z-slabs" % world,
-                                         (", int16 input" if args.i16 else "")
-                                         + ("" if list(args.spacing) == [1.0, 1.0, 1.0]
-                                            else ", spacing %s" % list(args.spacing))),
-                   "trig_mode": args.trig},
+                               "%s%s" % (nx, ny, nz, runner.config["input"], sigmas, args.mask,
+                                         args.layout,
+                                         "1 GPU" if not use_dist else
+                                         "%d Z-slabs, boundary-state hand-off, %d line groups per scale"
+                                         % (world, runner.config.get("line_groups", 1)),
+                                         "" if runner.config["spacing"] == [1.0, 1.0, 1.0]
+                                         else ", spacing %s" % runner.config["spacing"]),
+                   "trig_mode": args.trig,
+                   "trig_mode_meaning": {0: "double acos/cos (bit-faithful to the oracle)",
+                                         1: "float overloads, correctly rounded",
+                                         2: "float polynomials, max error 3.6e-7 |lambda1| "
+                                            "(bar: 1e-5)"}.get(args.trig)},
         "volume_level_Mvoxels_per_s": round(nvox / t_step / 1e6, 1),
         "roofline": roofline,
     }
@@ -234,6 +261,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(synth, seed, sigmas, args.cpu_sample)
         print(json.dumps(out), flush=True)
     if use_dist:
+        runner.finish()
+        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -265,6 +294,10 @@ class SingleGpuRunner:
         if args.zchunk:
             self.ctx.set_option(pkg.OPT_ZCHUNK, args.zchunk)
         self.ctx.reserve(shape)
+        self.config = {"input": "int16" if args.i16 else "float32", "spacing": list(self.spacing)}
+
+    def contexts(self):
+        return [self.ctx]
 
     def step(self):
         self.ctx.emphysema_features_device(

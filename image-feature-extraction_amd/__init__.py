@@ -39,7 +39,7 @@ EXPORTS = (
     "ife_fd_hessian_features", "ife_fd_gradient_features", "ife_mask_image_f64",
     "ife_get_kernel_times", "ife_reset_kernel_times",
     "ife_stage_prepare", "ife_stage_recursive_gaussian", "ife_stage_recursive_gaussian_batch",
-    "ife_stage_features",
+    "ife_stage_features", "ife_stage_z_ck_bytes", "ife_stage_z_sweep", "ife_stage_z_combine",
     "ife_sort_f32", "ife_equalized_edges_f32", "ife_equalized_edges_f64", "ife_dense_histogram_f32", "ife_roi_histograms", "ife_bag_image",
     "ife_samples_create", "ife_samples_destroy", "ife_samples_count", "ife_samples_clear",
     "ife_samples_add_features", "ife_samples_add_image", "ife_samples_sort",
@@ -110,6 +110,12 @@ def load_library():
     lib.ife_stage_recursive_gaussian_batch.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), vd,
                                                        i32, C.POINTER(C.c_double), i32]
     lib.ife_stage_features.argtypes = [vp, vp, vp, vp, i32, vd, i32, i32, vp, i32]
+    lib.ife_stage_z_ck_bytes.argtypes = [vd]
+    lib.ife_stage_z_ck_bytes.restype = C.c_size_t
+    lib.ife_stage_z_sweep.argtypes = [vp, i32, i32, C.POINTER(vp), vd, i64, i64,
+                                      C.POINTER(C.c_double), i32, vp, vp, C.POINTER(vp)]
+    lib.ife_stage_z_combine.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), vd, i64, i64,
+                                        C.POINTER(C.c_double), i32, i32, C.POINTER(vp)]
     lib.ife_get_kernel_times.argtypes = [vp, C.POINTER(KernelTime), i32]
     lib.ife_reset_kernel_times.argtypes = [vp]
     lib.ife_sort_f32.argtypes = [vp, vp, i64, vp, i32]
@@ -352,6 +358,34 @@ class Context:
             self._h, C.c_void_p(num_ptr), C.c_void_p(den_ptr or 0), C.c_void_p(mask_ptr or 0),
             mask_dtype, C.byref(d), int(bool(halo_lo)), int(bool(halo_hi)), C.c_void_p(out_ptr),
             layout))
+
+    def stage_z_ck_bytes(self, slab_shape_zyx):
+        d = _desc(slab_shape_zyx, (1.0, 1.0, 1.0))
+        return int(self._lib.ife_stage_z_ck_bytes(C.byref(d)))
+
+    def stage_z_sweep(self, direction, in_ptrs, slab_shape_zyx, spacing, line0, nlines, sigmas,
+                      has_neighbour, state_in_ptr, state_out_ptr, ck_ptrs):
+        """Causal (direction 0) or anticausal (1) sweep of the Z pass of a Z-slab."""
+        n = len(in_ptrs)
+        d = _desc(slab_shape_zyx, spacing)
+        ins = (C.c_void_p * n)(*in_ptrs)
+        cks = (C.c_void_p * n)(*ck_ptrs)
+        sg = (C.c_double * n)(*[float(s) for s in sigmas])
+        self._chk(self._lib.ife_stage_z_sweep(
+            self._h, int(direction), n, ins, C.byref(d), int(line0), int(nlines), sg,
+            int(bool(has_neighbour)), C.c_void_p(state_in_ptr or 0), C.c_void_p(state_out_ptr), cks))
+
+    def stage_z_combine(self, in_ptrs, out_ptrs, slab_shape_zyx, spacing, line0, nlines, sigmas,
+                        has_lo, has_hi, ck_ptrs):
+        n = len(in_ptrs)
+        d = _desc(slab_shape_zyx, spacing)
+        ins = (C.c_void_p * n)(*in_ptrs)
+        outs = (C.c_void_p * n)(*out_ptrs)
+        cks = (C.c_void_p * n)(*ck_ptrs)
+        sg = (C.c_double * n)(*[float(s) for s in sigmas])
+        self._chk(self._lib.ife_stage_z_combine(
+            self._h, n, ins, outs, C.byref(d), int(line0), int(nlines), sg, int(bool(has_lo)),
+            int(bool(has_hi)), cks))
 
     # ---- rows f1 / f2: sample columns, histogram edges, dense histograms --------------
     def sort_f32(self, values):

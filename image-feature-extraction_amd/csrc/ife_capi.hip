@@ -39,6 +39,8 @@ enum KernelKind {
   KK_IIR_Z = 0,
   KK_IIR_X,
   KK_IIR_Y,
+  KK_ZSLAB_SWEEP,
+  KK_ZSLAB_COMBINE,
   KK_FEATURES,
   KK_EIG_BATCH,
   KK_DIVIDE,
@@ -52,7 +54,7 @@ enum KernelKind {
   KK_HIST,
   KK_COUNT
 };
-const char *kKindNames[KK_COUNT] = {"iir_z", "iir_x", "iir_y", "features", "eig_batch",
+const char *kKindNames[KK_COUNT] = {"iir_z", "iir_x", "iir_y", "zslab_sweep", "zslab_combine", "features", "eig_batch",
                                     "divide", "mask_f64", "prep", "sort_hist", "sort_scan",
                                     "sort_scatter", "gather", "edges", "dense_histogram"};
 
@@ -363,6 +365,83 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
   if (ctx->iir_fma) IFE_LAUNCH_IIR(iir_fma);
   else IFE_LAUNCH_IIR(iir_exact);
 #undef IFE_LAUNCH_IIR
+  IFE_HIP(ctx, hipGetLastError());
+  return IFE_OK;
+}
+
+// ---- Z pass of a Z-slab (iir_types.hpp "ZSlabJob") -----------------------------------
+constexpr int ZSLAB_K = 12;  // register block of the slab kernels (fixes the checkpoint layout)
+int64_t zslab_pairs(int64_t n) { return ((n + ZSLAB_K - 1) / ZSLAB_K + 1) / 2; }
+size_t zslab_ck_bytes(const ife_volume_desc *v) {
+  return (size_t)zslab_pairs(v->nz) * 4 * (size_t)(v->nx * v->ny) * 2 * (sizeof(double) + sizeof(float));
+}
+// phase 0: causal sweep, 1: anticausal sweep, 2: combine
+int launch_zslab(ife_ctx *ctx, int phase, int njobs, const float *const *in, float *const *out,
+                 const ife_volume_desc *v, int64_t line0, int64_t nlines, const double *sigmas,
+                 int has_lo, int has_hi, const void *state_in, void *state_out, void *const *ck) {
+  if (njobs < 1 || njobs > IIR_MAX_JOBS) return fail(ctx, IFE_E_ARG, "bad job count %d", njobs);
+  const int64_t L = v->nx * v->ny, n = v->nz;
+  if (line0 < 0 || nlines < 1 || line0 + nlines > L)
+    return fail(ctx, IFE_E_ARG, "line range [%lld, %lld) outside the %lld lines of the slab",
+                (long long)line0, (long long)(line0 + nlines), (long long)L);
+  if (n < 4) return fail(ctx, IFE_E_SIZE, "a Z-slab needs at least 4 planes (got %lld)", (long long)n);
+  // 32-bit offsets of the buffer accesses (iir_kernels.inc "addressing")
+  if ((int64_t)2 * ZSLAB_K * L * 4 >= (int64_t)1 << 31 || L * 8 * 3 >= (int64_t)1 << 32)
+    return fail(ctx, IFE_E_SIZE, "slab too large for the 32-bit offsets of the line kernels");
+  if (!in || !sigmas || !ck) return fail(ctx, IFE_E_ARG, "null pointer");
+  const bool need_in = phase == 0 ? has_lo != 0 : phase == 1 ? has_hi != 0 : false;
+  if ((phase < 2 && !state_out) || (need_in && !state_in)) return fail(ctx, IFE_E_ARG, "null state buffer");
+  if ((reinterpret_cast<uintptr_t>(state_in) | reinterpret_cast<uintptr_t>(state_out)) % 8)
+    return fail(ctx, IFE_E_ARG, "state buffers must be aligned to 8 bytes");
+  const int64_t np = zslab_pairs(n);
+  ZSlabJobs jobs;
+  memset(&jobs, 0, sizeof jobs);
+  for (int j = 0; j < njobs; ++j) {
+    ZSlabJob &J = jobs.j[j];
+    if (!in[j] || !ck[j] || (phase == 2 && (!out || !out[j] || out[j] == in[j])))
+      return fail(ctx, IFE_E_ARG, "bad job buffers");
+    if (reinterpret_cast<uintptr_t>(ck[j]) % 8 || reinterpret_cast<uintptr_t>(in[j]) % 4)
+      return fail(ctx, IFE_E_ARG, "job buffers are misaligned");
+    J.in = in[j] + line0;
+    J.out = phase == 2 ? out[j] + line0 : nullptr;
+    double *cy = (double *)ck[j];
+    double *ay = cy + np * 4 * L;
+    float *cx = (float *)(ay + np * 4 * L);
+    float *ax = cx + np * 4 * L;
+    J.cy = cy + line0; J.ay = ay + line0; J.cx = cx + line0; J.ax = ax + line0;
+    const size_t rec = (size_t)nlines * 48;  // [4][nlines] doubles, then [4][nlines] floats
+    if (state_in) {
+      const char *b = (const char *)state_in + (size_t)j * rec;
+      J.sin_y = (const double *)b;
+      J.sin_x = (const float *)(b + (size_t)nlines * 32);
+    }
+    if (state_out) {
+      char *b = (char *)state_out + (size_t)j * rec;
+      J.sout_y = (double *)b;
+      J.sout_x = (float *)(b + (size_t)nlines * 32);
+    }
+    if (!(sigmas[j] > 0.0) || gauss_coeffs(sigmas[j], v->sz, &J.c))
+      return fail(ctx, IFE_E_ARG, "bad sigma or spacing");
+  }
+  ZSlabGeom g;
+  g.n = n; g.nlines = nlines; g.sstride = L; g.ck_stride = L;
+  g.has_lo = has_lo ? 1 : 0; g.has_hi = has_hi ? 1 : 0;
+  g.njobs = njobs;
+  g.ngroups = (int32_t)((nlines + 255) / 256);
+  const dim3 grid((unsigned)((g.ngroups + 7) / 8 * 8 * njobs), 1, 1);
+  ProfScope ps(ctx, phase == 2 ? KK_ZSLAB_COMBINE : KK_ZSLAB_SWEEP);
+#define IFE_LAUNCH_ZSLAB(NS)                                                                        \
+  do {                                                                                              \
+    if (phase == 0)                                                                                 \
+      hipLaunchKernelGGL((NS::zslab_causal_kernel<ZSLAB_K>), grid, dim3(256), 0, ctx->stream, jobs, g); \
+    else if (phase == 1)                                                                            \
+      hipLaunchKernelGGL((NS::zslab_anti_kernel<ZSLAB_K>), grid, dim3(256), 0, ctx->stream, jobs, g);   \
+    else                                                                                            \
+      hipLaunchKernelGGL((NS::zslab_combine_kernel<ZSLAB_K>), grid, dim3(256), 0, ctx->stream, jobs, g); \
+  } while (0)
+  if (ctx->iir_fma) IFE_LAUNCH_ZSLAB(iir_fma);
+  else IFE_LAUNCH_ZSLAB(iir_exact);
+#undef IFE_LAUNCH_ZSLAB
   IFE_HIP(ctx, hipGetLastError());
   return IFE_OK;
 }
@@ -962,6 +1041,34 @@ int ife_stage_recursive_gaussian_batch(ife_ctx *ctx, int njobs, const float *con
     return fail(ctx, IFE_E_SIZE, "the recursive Gaussian needs at least 4 voxels along axis %d",
                 axis);
   return launch_iir(ctx, vol, axis, njobs, in, out, sigmas, in_y_chunks);
+}
+
+size_t ife_stage_z_ck_bytes(const ife_volume_desc *slab) {
+  if (!slab || slab->nx <= 0 || slab->ny <= 0 || slab->nz <= 0) return 0;
+  return zslab_ck_bytes(slab);
+}
+
+int ife_stage_z_sweep(ife_ctx *ctx, int direction, int njobs, const float *const *in,
+                      const ife_volume_desc *slab, int64_t line0, int64_t nlines,
+                      const double *sigmas, int has_neighbour, const void *state_in,
+                      void *state_out, void *const *ck) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_vol(ctx, slab, false))) return rc;
+  if (direction != 0 && direction != 1) return fail(ctx, IFE_E_ARG, "direction must be 0 (causal) or 1 (anticausal)");
+  return launch_zslab(ctx, direction, njobs, in, nullptr, slab, line0, nlines, sigmas,
+                      direction == 0 ? has_neighbour : 0, direction == 1 ? has_neighbour : 0, state_in,
+                      state_out, ck);
+}
+
+int ife_stage_z_combine(ife_ctx *ctx, int njobs, const float *const *in, float *const *out,
+                        const ife_volume_desc *slab, int64_t line0, int64_t nlines,
+                        const double *sigmas, int has_lo, int has_hi, void *const *ck) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_vol(ctx, slab, false))) return rc;
+  return launch_zslab(ctx, 2, njobs, in, out, slab, line0, nlines, sigmas, has_lo, has_hi, nullptr,
+                      nullptr, ck);
 }
 
 int ife_stage_features(ife_ctx *ctx, const float *num, const float *den, const void *mask,

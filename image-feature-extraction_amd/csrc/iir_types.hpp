@@ -59,4 +59,35 @@ struct IirJobs {
   IirJob j[IIR_MAX_JOBS];
 };
 
+// ---- Z pass of a Z-slab (multi-GPU): the recursion state crosses the slab boundary -------
+// A slab holds planes [z0, z1) of every Z line.  The causal recursion enters from the slab
+// below with the state (y[z0-1..z0-4], x[z0-1..z0-3]) and leaves with the same record at
+// z1; the anticausal one enters from above with (y[z1..z1+3], x[z1..z1+3]) and leaves
+// with the record at z0.  A record is 4 doubles + 4 floats per line, struct-of-arrays:
+// y[k][line] (k = 0: nearest sample), then x[k][line].  Every pair of register blocks has
+// one causal checkpoint (the state in front of its first sample) and one anticausal
+// checkpoint (the state in front of its last sample, coming from above), so that the
+// combine kernel can rebuild both recursions of a pair from them -- the same sequential
+// arithmetic as the single-device kernel, sample for sample.
+struct ZSlabJob {
+  const float *in;
+  float *out;              // combine only
+  double *cy; float *cx;   // causal checkpoints      [npairs][4][ck_stride]
+  double *ay; float *ax;   // anticausal checkpoints  [npairs][4][ck_stride]
+  const double *sin_y; const float *sin_x;  // incoming state of the sweep, [4][nlines]
+  double *sout_y; float *sout_x;            // outgoing state of the sweep, [4][nlines]
+  IirCoef c;
+};
+struct ZSlabJobs {
+  ZSlabJob j[IIR_MAX_JOBS];
+};
+struct ZSlabGeom {
+  int64_t n;          // planes of the slab
+  int64_t nlines;     // lines of this launch (pointers are already offset to the first one)
+  int64_t sstride;    // elements between planes
+  int64_t ck_stride;  // lines of the checkpoint arrays
+  int32_t has_lo, has_hi;  // a slab below / above exists (else: ITK's border form)
+  int32_t njobs, ngroups;
+};
+
 }  // namespace ife

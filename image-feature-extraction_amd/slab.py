@@ -2,57 +2,105 @@
 
 The reference has no distributed code; this is the host-side
 orchestration the MI355X build adds.  One process per GPU (torch.distributed; backend
-"nccl" is RCCL over xGMI).  Rank g owns planes [g*nz/W, (g+1)*nz/W) of the volume and its
-slab of every output, so the concatenation of the ranks' outputs in rank order IS the
-reference's voxel order.
+"nccl" is RCCL over xGMI).  Rank r owns a contiguous range of planes of the volume (any
+cut with at least 4 planes per rank) and the same planes of every output, so the
+concatenation of the ranks' outputs in rank order IS the reference's voxel order.
 
-Per step (all scales):
-  exchange #0      all-to-all: Z-slabs -> Y-slabs of the raw image and mask (once per step)
-  prepare          Y-slab   tc = image*mask, cf = float(mask)              (local)
-  per scale:
-    Z pass         Y-slab   every Z line is whole inside a Y-slab          (local)
-    exchange #1    all-to-all: Y-slabs -> Z-slabs of the Z-pass output     (per field)
-    X, Y passes    Z-slab   lines are slab-local                           (local)
-    exchange #2    one boundary plane of num and den to each Z neighbour   (halo)
-    features       Z-slab   divide + gradient + Hessian + eigen + mask     (local)
+Everything is slab-local except two things:
 
-The Z recursion of ITK's recursive Gaussian runs the full length of every Z line, so it
-is the one stage a Z-slab cut cannot keep local.  Re-cutting the two smoothing inputs
-along Y for that pass keeps the arithmetic exactly the sequential recursion of the
-single-GPU path (results are bit-identical to it), at the price of moving 8 B/voxel/scale
-across xGMI; each rank talks to all W-1 peers at once, so all seven links carry
-traffic.  The Z pass of scale 0 runs first and its exchange
-starts at once; the Z passes of the other scales run batched in one launch (a slab has few
-lines per field) behind it, and their exchanges travel while scale 0 computes.
+  * the Z recursion of ITK's recursive Gaussian, which runs the full length of every Z
+    line.  It is kept exactly sequential by handing the recursion STATE across the slab
+    boundaries (C-ABI `ife_stage_z_sweep` / `ife_stage_z_combine`): the causal chain
+    travels rank 0 -> W-1, the anticausal chain W-1 -> 0, both at once, as records of
+    4 doubles + 4 floats per line and (scale, field); each rank then rebuilds both
+    recursions of its slab from checkpoints.  Stitched, this is bit for bit the
+    single-device result.
+  * the +-1 plane stencil of the feature kernel: one boundary plane of numerator and
+    denominator per scale to each Z neighbour.
+
+Per step and rank (S scales, nf = 2 fields with a mask, G line groups per scale):
+
+  prepare                       tc = image*mask, cf = float(mask)                (local)
+  chain stream, items (s, g) in expected-arrival order:
+      C(s, g): [recv state from r-1] causal sweep     [send state to r+1]
+      A(s, g): [recv state from r+1] anticausal sweep [send state to r-1]
+  bulk stream, per scale group:
+      combine (Z output), X pass, Y pass, halo exchange, features               (local)
+
+Bytes over xGMI per boundary, direction and step: 48 B x nx*ny x S x nf (512^2, 3 scales,
+2 fields: 75 MB) + one plane of 2 fields per scale (6 MB); neighbours only.
+
+The order of the sweeps on a rank is static: sorted by the hop count after which the state
+can arrive (causal item i at rank r: r + i; anticausal: W-1-r + i; ties causal first).
+Every dependency points to an event with a smaller key on the neighbour, so blocking waits
+in that order cannot form a cycle -- the schedule is deadlock-free whether a wait blocks a
+stream (RCCL) or the host (gloo in the tests).
 
 Nothing here touches the oracle: `stages` is the C-ABI (HipStages).  Tests substitute
 their own stage object to exercise this orchestration on CPU with gloo.
 """
+import contextlib
+
 import numpy as np
+
+STATE_BYTES_PER_LINE = 48  # 4 doubles + 4 floats (include/ife_hip.h, ife_stage_z_sweep)
+
+
+def slab_bounds(nz, world):
+    """Default cut: nz // world planes each, the remainder spread over the first ranks."""
+    q, rem = divmod(nz, world)
+    b = [0]
+    for r in range(world):
+        b.append(b[-1] + q + (1 if r < rem else 0))
+    return b
+
+
+def sweep_schedule(rank, world, n_items):
+    """[(direction, item)] in the order this rank runs its sweeps (module docstring)."""
+    ev = []
+    for i in range(n_items):
+        ev.append((rank + i, 0, i))
+        ev.append((world - 1 - rank + i, 1, i))
+    ev.sort()
+    return [(d, i) for _, d, i in ev]
 
 
 class HipStages:
-    """Stage calls through the C-ABI on torch device tensors."""
+    """Stage calls through the C-ABI on torch device tensors.  `ctx` runs the bulk work,
+    `chain_ctx` (bound to another stream; may be the same context) the boundary sweeps."""
 
-    def __init__(self, pkg, ctx):
-        self.pkg, self.ctx = pkg, ctx
+    def __init__(self, pkg, ctx, chain_ctx=None):
+        self.pkg, self.ctx, self.chain_ctx = pkg, ctx, chain_ctx or ctx
 
-    def prepare(self, img, mask, tc, cf, y_chunks):
-        """tc/cf are written in all-to-all send order [y_chunks][nzl][ny/y_chunks][nx]."""
+    def ck_bytes(self, slab_shape):
+        return self.ctx.stage_z_ck_bytes(slab_shape)
+
+    def prepare(self, img, mask, tc, cf):
         pkg = self.pkg
         idt = pkg.F32 if img.element_size() == 4 else pkg.I16
         mdt = pkg.U8 if mask is None or mask.element_size() == 1 else pkg.U16
         self.ctx.stage_prepare(img.data_ptr(), idt, mask.data_ptr() if mask is not None else None,
                                mdt, tuple(img.shape), tc.data_ptr(),
-                               cf.data_ptr() if cf is not None else None, y_chunks)
+                               cf.data_ptr() if cf is not None else None, 1)
 
-    def gaussian_axis_batch(self, srcs, dsts, spacing, axis, sigmas, in_y_chunks=1):
-        """One launch over several float volumes (jobs) shaped like dsts[0].  With
-        in_y_chunks = W the sources are [W][nzl][ny/W][nx] as an all-to-all left them."""
+    def z_sweep(self, direction, srcs, spacing, sigmas, line0, nlines, has_neighbour, state_in,
+                state_out, cks):
+        self.chain_ctx.stage_z_sweep(direction, [t.data_ptr() for t in srcs], tuple(srcs[0].shape),
+                                     spacing, line0, nlines, sigmas, has_neighbour,
+                                     state_in.data_ptr() if has_neighbour else None,
+                                     state_out.data_ptr(), [c.data_ptr() for c in cks])
+
+    def z_combine(self, srcs, dsts, spacing, sigmas, has_lo, has_hi, cks):
+        shape = tuple(srcs[0].shape)
+        self.ctx.stage_z_combine([t.data_ptr() for t in srcs], [t.data_ptr() for t in dsts], shape,
+                                 spacing, 0, shape[1] * shape[2], sigmas, has_lo, has_hi,
+                                 [c.data_ptr() for c in cks])
+
+    def gaussian_axis_batch(self, srcs, dsts, spacing, axis, sigmas):
+        """One launch over several float volumes (jobs) shaped like dsts[0]."""
         self.ctx.stage_recursive_gaussian_batch([t.data_ptr() for t in srcs],
                                                 [t.data_ptr() for t in dsts],
-                                                tuple(dsts[0].shape), spacing, axis, sigmas,
-                                                in_y_chunks)
+                                                tuple(dsts[0].shape), spacing, axis, sigmas, 1)
 
     def features(self, num, den, mask, slab_shape, spacing, halo_lo, halo_hi, out, layout):
         mdt = self.pkg.U8 if mask is None or mask.element_size() == 1 else self.pkg.U16
@@ -61,147 +109,252 @@ class HipStages:
                                 spacing, halo_lo, halo_hi, out.data_ptr(), layout)
 
 
+class _Xfer:
+    """A pending point-to-point transfer; wait() blocks the current stream (RCCL) or the host
+    (gloo) and then runs the completion hook (host staging copies back to the device)."""
+
+    def __init__(self, work, after=None, keep=None):
+        self.work, self.after, self.keep = work, after, keep
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if self.after is not None:
+            self.after()
+            self.after = None
+        self.keep = None
+
+
 class TorchComm:
-    """The two exchanges, over torch.distributed.  `host_staging` moves data through host
-    memory (for backends that cannot take device tensors, e.g. gloo in the tests)."""
+    """Neighbour exchanges over torch.distributed.  Every edge (r, r+1) has one communicator
+    per traffic class -- causal states up, anticausal states down, stencil planes -- so that
+    no class queues behind another on a shared communicator stream.  `host_staging` moves
+    data through host memory (for backends that cannot take device tensors: gloo with the
+    ranks of a test sharing one GPU)."""
 
     def __init__(self, dist, rank, world, host_staging=False):
         self.dist, self.rank, self.world, self.host = dist, rank, world, host_staging
-        # The halo planes travel on their own communicator: on the default one they would
-        # queue behind the all-to-alls of the later scales, which are issued up front.
-        self.halo_group = dist.new_group(list(range(world))) if world > 1 else None
+        self.up, self.down, self.halo_g = [], [], []
+        for e in range(world - 1):  # collective: every rank creates every group, same order
+            self.up.append(dist.new_group([e, e + 1]))
+            self.down.append(dist.new_group([e, e + 1]))
+            self.halo_g.append(dist.new_group([e, e + 1]))
 
-    def all_to_all(self, send, recv, async_op=False):
-        """send/recv: contiguous [world, ...]; chunk h of send goes to rank h."""
-        dist = self.dist
+    def _isend(self, buf, dst, group):
         if self.host:
-            s, r = send.cpu(), recv.cpu()
+            h = buf.cpu()
+            return _Xfer(self.dist.isend(h, dst, group=group), keep=h)
+        return _Xfer(self.dist.isend(buf, dst, group=group))
+
+    def _irecv(self, buf, src, group):
+        if self.host:
+            import torch
+            h = torch.empty(buf.shape, dtype=buf.dtype, device="cpu")
+            return _Xfer(self.dist.irecv(h, src, group=group), after=lambda: buf.copy_(h), keep=h)
+        return _Xfer(self.dist.irecv(buf, src, group=group))
+
+    # causal states travel up (r -> r+1), anticausal states down (r -> r-1)
+    def isend_up(self, buf):
+        return self._isend(buf, self.rank + 1, self.up[self.rank])
+
+    def irecv_up(self, buf):
+        return self._irecv(buf, self.rank - 1, self.up[self.rank - 1])
+
+    def isend_down(self, buf):
+        return self._isend(buf, self.rank - 1, self.down[self.rank - 1])
+
+    def irecv_down(self, buf):
+        return self._irecv(buf, self.rank + 1, self.down[self.rank])
+
+    def halo(self, first_planes, last_planes, lo_halos, hi_halos):
+        """Send my first planes to rank-1 (its hi halos) and my last planes to rank+1 (its lo
+        halos); receive mine.  Lists of equal length (one entry per field and scale); edge
+        ranks skip the missing side.  One batched call per neighbour."""
+        dist = self.dist
+        works, post = [], []
+        for nb, snd, rcv in ((self.rank - 1, first_planes, lo_halos),
+                             (self.rank + 1, last_planes, hi_halos)):
+            if nb < 0 or nb >= self.world:
+                continue
+            g = self.halo_g[min(nb, self.rank)]
             ops = []
-            for h in range(self.world):
-                if h == self.rank:
-                    r[h].copy_(s[h])
-                else:
-                    ops.append(dist.P2POp(dist.isend, s[h], h))
-                    ops.append(dist.P2POp(dist.irecv, r[h], h))
-            for w in (dist.batch_isend_irecv(ops) if ops else []):
-                w.wait()
-            recv.copy_(r)
-            return None
-        return dist.all_to_all_single(recv, send, async_op=async_op)
-
-    def halo(self, first_plane, last_plane, lo_halo, hi_halo):
-        """Send my first plane to rank-1 (its hi halo) and my last plane to rank+1 (its lo
-        halo); receive mine.  Edge ranks skip the missing side."""
-        dist = self.dist
-        ops, post = [], []
-        lo, hi = self.rank - 1, self.rank + 1
-        if self.host:
-            fp, lp = first_plane.cpu(), last_plane.cpu()
-            lo_b, hi_b = lo_halo.cpu(), hi_halo.cpu()
-        else:
-            fp, lp, lo_b, hi_b = first_plane, last_plane, lo_halo, hi_halo
-        g = self.halo_group
-        if lo >= 0:
-            ops += [dist.P2POp(dist.isend, fp, lo, group=g), dist.P2POp(dist.irecv, lo_b, lo, group=g)]
-            post.append((lo_halo, lo_b))
-        if hi < self.world:
-            ops += [dist.P2POp(dist.isend, lp, hi, group=g), dist.P2POp(dist.irecv, hi_b, hi, group=g)]
-            post.append((hi_halo, hi_b))
-        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            for s, r in zip(snd, rcv):
+                if self.host:
+                    import torch
+                    sh, rh = s.cpu(), torch.empty(r.shape, dtype=r.dtype, device="cpu")
+                    post.append((r, rh, sh))
+                    s, r = sh, rh
+                ops += [dist.P2POp(dist.isend, s, nb, group=g), dist.P2POp(dist.irecv, r, nb, group=g)]
+            works += dist.batch_isend_irecv(ops)
+        for w in works:
             w.wait()
-        if self.host:
-            for dst, src in post:
-                dst.copy_(src)
+        for dst, src, _ in post:
+            dst.copy_(src)
+
+
+class _Streams:
+    """Two HIP streams on a GPU (boundary sweeps ahead of bulk kernels) or nothing on CPU."""
+
+    def __init__(self, torch, dev, two_streams):
+        self.torch = torch
+        self.gpu = dev is not None and dev.type == "cuda"
+        self.bulk = torch.cuda.current_stream(dev) if self.gpu else None
+        self.chain = (torch.cuda.Stream(dev, priority=-1) if two_streams else self.bulk) if self.gpu else None
+        self.post = torch.cuda.Stream(dev) if self.gpu and two_streams else self.bulk
+
+    def on(self, stream):
+        return self.torch.cuda.stream(stream) if self.gpu else contextlib.nullcontext()
+
+    def record(self, stream):
+        if not self.gpu:
+            return None
+        e = self.torch.cuda.Event()
+        e.record(stream)
+        return e
+
+    def wait(self, stream, event):
+        if self.gpu and event is not None:
+            stream.wait_event(event)
 
 
 class SlabEngine:
     """Runs all scales of the feature path on this rank's Z-slab."""
 
-    def __init__(self, stages, comm, shape_zyx, spacing, sigmas, rank, world, empty, layout,
-                 has_mask=True, overlap=True):
+    def __init__(self, stages, comm, shape_zyx, spacing, sigmas, rank, world, alloc, layout,
+                 has_mask=True, overlap=True, line_groups=None, bounds=None, streams=None):
+        """alloc(shape, dtype_name) -> tensor ('float32' or 'uint8') on the compute device;
+        bounds: W+1 plane indices (default: slab_bounds); line_groups: items per scale on the
+        boundary chains (default 2 when world > 2, else 1); streams: a _Streams (GPU)."""
         nz, ny, nx = shape_zyx
-        if nz % world or ny % world:
-            raise ValueError("nz=%d and ny=%d must be multiples of the number of slabs %d"
-                             % (nz, ny, world))
-        if min(nz, ny, nx) < 4:
+        self.bounds = list(bounds) if bounds is not None else slab_bounds(nz, world)
+        if len(self.bounds) != world + 1 or self.bounds[0] != 0 or self.bounds[-1] != nz:
+            raise ValueError("bounds must run from 0 to nz in world+1 steps")
+        if min(b1 - b0 for b0, b1 in zip(self.bounds, self.bounds[1:])) < 4:
+            raise ValueError("every Z-slab needs at least 4 planes (nz=%d over %d ranks: %s)"
+                             % (nz, world, self.bounds))
+        if min(ny, nx) < 4:
             raise ValueError("the recursive Gaussian needs at least 4 voxels along every axis")
-        self.st, self.comm = stages, comm
+        self.st, self.comm, self.sync = stages, comm, streams
         self.nz, self.ny, self.nx, self.W, self.rank = nz, ny, nx, world, rank
-        self.nzl, self.nyl = nz // world, ny // world
+        self.z0, self.z1 = self.bounds[rank], self.bounds[rank + 1]
+        self.nzl = nzl = self.z1 - self.z0
         self.spacing, self.sigmas, self.layout = tuple(spacing), list(sigmas), layout
         self.has_mask, self.overlap = has_mask, overlap
-        nzl, nyl, W = self.nzl, self.nyl, world
-        f = lambda *shp: empty(shp)  # float32 buffers
-        nf = 2 if has_mask else 1
+        self.nf = nf = 2 if has_mask else 1
         S = len(self.sigmas)
-        self.group = 4 if nf == 2 else 8              # scales per line-kernel launch (<= 8 jobs)
-        if nyl % 64 and world > 1:
-            raise ValueError("ny/world = %d must be a multiple of 64 (wave-aligned Y chunks)" % nyl)
-        self.raw = None                                           # raw image / mask exchange buffers
-        self.src_y = [f(W, nzl, nyl, nx) for _ in range(nf)]      # tc, cf (Y-slab == [nz][nyl][nx])
-        # per scale: Z-pass output (Y-slab) and its Y-chunked Z-slab image after exchange #1
-        self.zy = [[f(W, nzl, nyl, nx) for _ in range(nf)] for _ in range(S)]
-        self.zz = [[f(W, nzl, nyl, nx) for _ in range(nf)] for _ in range(S)]
-        self.b = [f(nzl, ny, nx) for _ in range(nf)]              # X-pass output
-        self.pad = [f(nzl + 2, ny, nx) for _ in range(nf)]        # Y-pass output + halo planes
+        L = ny * nx
+        G = line_groups if line_groups is not None else (2 if world > 2 else 1)
+        G = max(1, min(G, (L + 255) // 256))
+        per = ((L + G - 1) // G + 255) // 256 * 256  # whole workgroups of 256 lines
+        self.groups = [(l0, min(L, l0 + per) - l0) for l0 in range(0, L, per)]
+        self.items = [(s, g) for s in range(S) for g in range(len(self.groups))]
+        self.schedule = sweep_schedule(rank, world, len(self.items))
+        f = lambda *shp: alloc(shp, "float32")
+        self.src = [f(nzl, ny, nx) for _ in range(nf)]                      # tc, cf
+        self.zo = [[f(nzl, ny, nx) for _ in range(nf)] for _ in range(S)]   # Z-pass output
+        self.xo = [[f(nzl, ny, nx) for _ in range(nf)] for _ in range(S)]   # X-pass output
+        self.pad = [[f(nzl + 2, ny, nx) for _ in range(nf)] for _ in range(S)]  # Y output + halo planes
+        ckb = stages.ck_bytes((nzl, ny, nx))
+        self.ck = [[alloc((ckb,), "uint8") for _ in range(nf)] for _ in range(S)]
+        sb = lambda nl: alloc((nf * STATE_BYTES_PER_LINE * nl,), "uint8")
+        self.c_in = [sb(self.groups[g][1]) for _, g in self.items]
+        self.c_out = [sb(self.groups[g][1]) for _, g in self.items]
+        self.a_in = [sb(self.groups[g][1]) for _, g in self.items]
+        self.a_out = [sb(self.groups[g][1]) for _, g in self.items]
+        n = len(self.items)
+        self.sent = [[None] * n, [None] * n]      # pending sends of the previous step
+        self.consumed = [[None] * n, [None] * n]  # events: in-state read by its sweep
+        # scales of the bulk phase: the first alone (it can start while the states of the later
+        # ones are still travelling), the rest in launches of up to 8 jobs
+        per_launch = max(1, 8 // nf)
+        self.scale_groups = [[0]] + [list(range(s0, min(S, s0 + per_launch)))
+                                     for s0 in range(1, S, per_launch)]
 
+    # ---- one step -------------------------------------------------------------------
     def run(self, img_slab, mask_slab, out):
         """img_slab [nzl][ny][nx] f32|i16, mask_slab same shape u8|u16 or None,
         out [S][nzl][ny][nx][8] (or [S][8][nzl][ny][nx] planar) float32."""
-        st, comm = self.st, self.comm
-        nf = 2 if self.has_mask else 1
-        yshape = (self.nz, self.nyl, self.nx)
-        sp = self.spacing
-        S = len(self.sigmas)
-        # exchange #0 moves the RAW slab (image 4 or 2 B + mask 1 or 2 B per voxel, not the
-        # 8 B of two float fields) re-cut along Y; Cast + Multiply then run on the Y-slab
-        if self.raw is None:
-            import torch
-            mk = lambda t: (torch.empty((self.W, self.nzl, self.nyl, self.nx), dtype=t.dtype,
-                                        device=t.device),
-                            torch.empty((self.W, self.nzl, self.nyl, self.nx), dtype=t.dtype,
-                                        device=t.device))
-            self.raw = [mk(img_slab), mk(mask_slab) if self.has_mask else None]
-        for t, bufs in ((img_slab, self.raw[0]), (mask_slab if self.has_mask else None, self.raw[1])):
-            if t is None:
-                continue
-            send, recv = bufs
-            send.copy_(t.view(self.nzl, self.W, self.nyl, self.nx).permute(1, 0, 2, 3))
-            comm.all_to_all(send, recv)
-        st.prepare(self.raw[0][1].view(yshape),
-                   self.raw[1][1].view(yshape) if self.has_mask else None,
-                   self.src_y[0].view(yshape), self.src_y[1].view(yshape) if self.has_mask else None, 1)
-        # Z passes and exchanges #1.  Scale 0 goes alone so that its exchange is on the wire
-        # while the remaining scales run their Z pass in ONE launch (a slab has few lines per
-        # field: one job per launch would leave most of the device idle); the exchanges of
-        # scales 1.. then travel while scale 0 runs its X/Y/feature kernels.
-        groups = [[0]] + [list(range(s0, min(S, s0 + self.group)))
-                          for s0 in range(1, S, self.group)]
-        pending = [None] * S
-        for ss in groups:
-            st.gaussian_axis_batch([self.src_y[k].view(yshape) for s in ss for k in range(nf)],
-                                   [self.zy[s][k].view(yshape) for s in ss for k in range(nf)],
-                                   sp, 2, [self.sigmas[s] for s in ss for k in range(nf)])
+        st, comm, sy = self.st, self.comm, self.sync
+        nf, sp, W, r = self.nf, self.spacing, self.W, self.rank
+        has_lo, has_hi = r > 0, r < W - 1
+        slab_shape = (self.nzl, self.ny, self.nx)
+        on = sy.on if sy is not None else (lambda s: contextlib.nullcontext())
+        chain = sy.chain if sy is not None else None
+        bulk = sy.bulk if sy is not None else None
+        post = sy.post if sy is not None else None
+        rec = (lambda s: sy.record(s)) if sy is not None else (lambda s: None)
+        wait = (lambda s, e: sy.wait(s, e)) if sy is not None else (lambda s, e: None)
+        n = len(self.items)
+
+        st.prepare(img_slab, mask_slab if self.has_mask else None, self.src[0],
+                   self.src[1] if self.has_mask else None)
+        prepared = rec(bulk)
+
+        # receives of the whole step, posted where nothing else is queued: each edge and class
+        # has its own communicator, and a buffer is only written again once the sweep that read
+        # it in the previous step has finished
+        recv = [[None] * n, [None] * n]
+        with on(post):
+            for i in range(n):
+                if has_lo:
+                    wait(post, self.consumed[0][i])
+                    recv[0][i] = comm.irecv_up(self.c_in[i])
+                if has_hi:
+                    wait(post, self.consumed[1][i])
+                    recv[1][i] = comm.irecv_down(self.a_in[i])
+
+        swept = [[None] * n, [None] * n]
+        with on(chain):
+            wait(chain, prepared)
+            for d, i in self.schedule:
+                s, g = self.items[i]
+                l0, nl = self.groups[g]
+                has_nb = has_lo if d == 0 else has_hi
+                sin = (self.c_in if d == 0 else self.a_in)[i]
+                sout = (self.c_out if d == 0 else self.a_out)[i]
+                if has_nb:
+                    recv[d][i].wait()
+                if self.sent[d][i] is not None:  # last step's send still reads sout
+                    self.sent[d][i].wait()
+                    self.sent[d][i] = None
+                st.z_sweep(d, self.src[:nf], sp, [self.sigmas[s]] * nf, l0, nl, has_nb, sin, sout,
+                           self.ck[s][:nf])
+                swept[d][i] = rec(chain)
+                self.consumed[d][i] = swept[d][i]
+                if d == 0 and has_hi:
+                    self.sent[d][i] = comm.isend_up(sout)
+                elif d == 1 and has_lo:
+                    self.sent[d][i] = comm.isend_down(sout)
+
+        first = 0 if has_lo else 1
+        for ss in self.scale_groups:
+            for i, (s, g) in enumerate(self.items):
+                if s in ss:
+                    wait(bulk, swept[0][i])
+                    wait(bulk, swept[1][i])
+            sg = [self.sigmas[s] for s in ss for _ in range(nf)]
+            jobs = lambda bufs: [bufs[s][k] for s in ss for k in range(nf)]
+            st.z_combine([self.src[k] for s in ss for k in range(nf)], jobs(self.zo), sp, sg,
+                         has_lo, has_hi, jobs(self.ck))
+            st.gaussian_axis_batch(jobs(self.zo), jobs(self.xo), sp, 0, sg)
+            st.gaussian_axis_batch(jobs(self.xo), [self.pad[s][k][1:self.nzl + 1] for s in ss
+                                                   for k in range(nf)], sp, 1, sg)
+            pads = jobs(self.pad)
+            comm.halo([p[1] for p in pads], [p[self.nzl] for p in pads],
+                      [p[0] for p in pads], [p[self.nzl + 1] for p in pads])
             for s in ss:
-                pending[s] = [comm.all_to_all(self.zy[s][k], self.zz[s][k],
-                                              async_op=self.overlap) for k in range(nf)]
-        lo = 1 if self.rank > 0 else 0
-        hi = 1 if self.rank < self.W - 1 else 0
-        first = 0 if lo else 1
-        for s in range(S):                                    # X, Y, halo, features of scale s
-            for w in pending[s]:
-                if w is not None:
-                    w.wait()
-            sg = [self.sigmas[s]] * nf
-            # the x pass reads the Y-chunked buffers the exchange left and writes plain slabs
-            st.gaussian_axis_batch(self.zz[s][:nf], self.b[:nf], sp, 0, sg, self.W)
-            st.gaussian_axis_batch(self.b[:nf], [p[1:self.nzl + 1] for p in self.pad[:nf]], sp, 1, sg)
-            for k in range(nf):                               # exchange #2
-                p = self.pad[k]
-                comm.halo(p[1], p[self.nzl], p[0], p[self.nzl + 1])
-            st.features(self.pad[0][first:], self.pad[1][first:] if self.has_mask else None,
-                        mask_slab if self.has_mask else None, (self.nzl, self.ny, self.nx), sp,
-                        lo, hi, out[s], self.layout)
+                st.features(self.pad[s][0][first:], self.pad[s][1][first:] if self.has_mask else None,
+                            mask_slab if self.has_mask else None, slab_shape, sp,
+                            1 if has_lo else 0, 1 if has_hi else 0, out[s], self.layout)
+
+    def finish(self):
+        """Wait for the sends of the last step (call before tearing the process group down)."""
+        for d in (0, 1):
+            for i, x in enumerate(self.sent[d]):
+                if x is not None:
+                    x.wait()
+                    self.sent[d][i] = None
 
 
 class SlabRunner:
@@ -212,9 +365,11 @@ class SlabRunner:
         import torch
         import torch.distributed as dist
         nz, ny, nx = shape
-        nzl = nz // world
-        z0 = rank * nzl
-        img = synth.volume_f32((nzl, ny, nx), seed, z0=z0)
+        bounds = slab_bounds(nz, world)
+        z0, nzl = bounds[rank], bounds[rank + 1] - bounds[rank]
+        i16 = bool(getattr(args, "i16", False))
+        spacing = tuple(getattr(args, "spacing", (1.0, 1.0, 1.0)))
+        img = (synth.volume_i16 if i16 else synth.volume_f32)((nzl, ny, nx), seed, z0=z0)
         if mask_kind == "ellipsoids":
             mask = np.minimum(synth.mask_ellipsoids((nzl, ny, nx), z0=z0, nz_total=nz), 1)
             mask = mask.astype(np.uint8)
@@ -225,17 +380,39 @@ class SlabRunner:
         oshape = ((len(sigmas), nzl, ny, nx, 8) if layout == pkg.INTERLEAVED
                   else (len(sigmas), 8, nzl, ny, nx))
         self.d_out = torch.empty(oshape, dtype=torch.float32, device=dev)
+        self.streams = _Streams(torch, dev, two_streams=world > 1)
         self.ctx = pkg.Context(dev.index or 0)
-        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        self.ctx.set_option(pkg.OPT_TRIG_MODE, args.trig)
-        if args.iir_block:
-            self.ctx.set_option(pkg.OPT_IIR_BLOCK, args.iir_block)
-        if args.zchunk:
-            self.ctx.set_option(pkg.OPT_ZCHUNK, args.zchunk)
-        empty = lambda shp: torch.empty(shp, dtype=torch.float32, device=dev)
-        self.engine = SlabEngine(HipStages(pkg, self.ctx), TorchComm(dist, rank, world), shape,
-                                 (1.0, 1.0, 1.0), sigmas, rank, world, empty, layout,
-                                 has_mask=self.d_mask is not None)
+        self.ctx.set_stream(self.streams.bulk.cuda_stream)
+        self.chain_ctx = self.ctx
+        if self.streams.chain is not self.streams.bulk:
+            self.chain_ctx = pkg.Context(dev.index or 0)
+            self.chain_ctx.set_stream(self.streams.chain.cuda_stream)
+        for c in {id(self.ctx): self.ctx, id(self.chain_ctx): self.chain_ctx}.values():
+            c.set_option(pkg.OPT_TRIG_MODE, args.trig)
+            if getattr(args, "iir_block", None):
+                c.set_option(pkg.OPT_IIR_BLOCK, args.iir_block)
+            if getattr(args, "iir_ckpt", None):
+                c.set_option(pkg.OPT_IIR_CKPT, args.iir_ckpt)
+            if getattr(args, "iir_fma", False):
+                c.set_option(pkg.OPT_IIR_FMA, 1)
+            if getattr(args, "zchunk", None):
+                c.set_option(pkg.OPT_ZCHUNK, args.zchunk)
+        dt = {"float32": torch.float32, "uint8": torch.uint8}
+        alloc = lambda shp, d: torch.empty(shp, dtype=dt[d], device=dev)
+        self.engine = SlabEngine(HipStages(pkg, self.ctx, self.chain_ctx),
+                                 TorchComm(dist, rank, world), shape, spacing, sigmas, rank, world,
+                                 alloc, layout, has_mask=self.d_mask is not None,
+                                 streams=self.streams,
+                                 line_groups=getattr(args, "line_groups", None))
+        # what was actually built, for the bench line
+        self.config = {"input": "int16" if i16 else "float32", "spacing": list(spacing),
+                       "slab_planes": nzl, "line_groups": len(self.engine.groups)}
 
     def step(self):
         self.engine.run(self.d_img, self.d_mask, self.d_out)
+
+    def contexts(self):
+        return [self.ctx] if self.chain_ctx is self.ctx else [self.ctx, self.chain_ctx]
+
+    def finish(self):
+        self.engine.finish()

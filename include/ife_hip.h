@@ -223,6 +223,32 @@ int ife_stage_recursive_gaussian(ife_ctx *ctx, const float *in, float *out,
 int ife_stage_recursive_gaussian_batch(ife_ctx *ctx, int njobs, const float *const *in,
                                        float *const *out, const ife_volume_desc *vol, int axis,
                                        const double *sigmas, int in_y_chunks);
+/* The Z pass of a Z-slab with the recursion state handed across the slab boundaries (the
+ * reference has no counterpart: its RecursiveGaussianImageFilter sees whole lines,
+ * NormalizedGaussianConvolutionImageFilter.hxx:51-55).  A slab holds planes [z0, z1) of every
+ * Z line; `in` are njobs (<= 8) float slabs [nz][ny][nx] with one sigma each.  Three calls:
+ *   ife_stage_z_sweep(direction 0): causal recursion upwards.  has_neighbour = a slab below
+ *     exists and state_in holds its outgoing record; else ITK's start-of-line rule applies.
+ *     Leaves the causal checkpoints in ck[job] and the state at z1 in state_out.
+ *   ife_stage_z_sweep(direction 1): anticausal recursion downwards, state_in from the slab
+ *     above (or ITK's end-of-line rule); anticausal checkpoints, state at z0 in state_out.
+ *   ife_stage_z_combine: rebuilds both recursions of every block pair from the checkpoints
+ *     and writes float(causal + anticausal) to out[job].
+ * Stitched over the slabs this is bit for bit the sequential recursion of the whole line.
+ * Lines [line0, line0 + nlines) of the nx*ny lines are processed (x-fastest line index), so
+ * that a host can pipeline groups of lines across devices.  A state buffer holds, per job,
+ * 4*nlines doubles y[k][line] then 4*nlines floats x[k][line] (48*nlines bytes; 8-byte
+ * aligned).  ck[job] points at ife_stage_z_ck_bytes(slab) bytes of device memory that must
+ * survive from the sweeps to the combine.  Every slab needs at least 4 planes. */
+size_t ife_stage_z_ck_bytes(const ife_volume_desc *slab);
+int ife_stage_z_sweep(ife_ctx *ctx, int direction, int njobs, const float *const *in,
+                      const ife_volume_desc *slab, int64_t line0, int64_t nlines,
+                      const double *sigmas, int has_neighbour, const void *state_in,
+                      void *state_out, void *const *ck);
+int ife_stage_z_combine(ife_ctx *ctx, int njobs, const float *const *in, float *const *out,
+                        const ife_volume_desc *slab, int64_t line0, int64_t nlines,
+                        const double *sigmas, int has_lo, int has_hi, void *const *ck);
+
 /* Everything after the smoothing (ImageToEmphysemaFeaturesFilter.hxx:27-54 plus the
  * Divide of NormalizedGaussianConvolutionImageFilter.hxx:57-61) on a slab of slab->nz
  * planes.  num/den hold halo_lo + slab->nz + halo_hi planes: with halo_lo (halo_hi) = 1

@@ -42,8 +42,13 @@ def test_single_gpu_line():
 
 
 def test_slab_engine_line_with_one_rank():
-    """The multi-GPU engine (RCCL all-to-all with itself) prints the same contract."""
+    """The multi-GPU engine (one rank: no neighbour, so no transfer) prints the same contract,
+    and its description comes from what the runner built."""
     d = run_bench("--gpus", "1", "--steps", "1", "--warmup", "1", "--size", "64", "64", "64",
-                  "--force-slab", "--no-cpu-baseline")
-    assert d["n_gpus"] == 1 and d["value"] > 0 and "Z-slabs" not in d["config"]["workload"]
+                  "--force-slab", "--no-cpu-baseline", "--i16", "--spacing", "0.7", "0.7", "1.0")
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    w = d["config"]["workload"]
+    assert "1 Z-slabs" in w and "int16" in w and "spacing [0.7, 0.7, 1.0]" in w
+    assert set(d["roofline"]["kernels"]) >= {"zslab_sweep", "zslab_combine", "iir_x", "iir_y", "features"}
+    assert d["roofline"]["kernels"]["iir_x"]["issue_floor_ms"] > 0
     assert "cpu_baseline" not in d

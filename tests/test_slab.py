@@ -1,10 +1,13 @@
-"""Z-slab orchestration (image-feature-extraction_amd/slab.py).
+"""Z-slab orchestration (image-feature-extraction_amd/slab.py): boundary-state hand-off.
 
-CPU (gloo, world_size 2 and 4): the exchange logic is exercised with a stage object
-backed by the oracle, and the stitched slabs must equal the single-process oracle run bit
-for bit.  GPU (-m gpu): the same engine with the HIP stages, ranks sharing the one GPU of
-the test box and exchanging through gloo/host memory, must equal the single-GPU HIP run
-bit for bit.  (The RCCL path itself is only run by bench.py on a multi-GPU node.)
+CPU (gloo, world_size 2, 3 and 4): the engine runs with a stage object backed by the
+oracle's arithmetic, CPU tensors go through gloo's isend/irecv directly (the same comm
+branch RCCL takes: `host_staging=False`), and the stitched slabs must equal the
+single-process oracle run bit for bit -- including uneven cuts and several line groups per
+scale.  GPU (-m gpu): the same engine with the HIP stages, two HIP streams, the ranks
+sharing the one GPU of the test box and exchanging through gloo/host memory, must equal
+the single-GPU HIP run bit for bit.  (The RCCL transport itself is only run by bench.py
+on a multi-GPU node: unmeasured on hardware until the driver has one.)
 """
 import importlib
 import os
@@ -27,36 +30,107 @@ def _free_port():
 
 
 class OracleStages:
-    """Test double for slab.HipStages: the same three stages computed by the CPU oracle."""
+    """Test double for slab.HipStages: the stages computed on the CPU.  The Z sweeps restate
+    oracle/ife_oracle.c:ife_or_iir_line (itself ITK's FilterDataArray) for a SEGMENT of a line
+    with the recursion state passed in and out, vectorised over lines in numpy (every
+    multiply and add rounds on its own, as in the -ffp-contract=off C build); the "checkpoint"
+    of this double is simply the whole double-precision recursion output."""
 
     def __init__(self, oracle):
         self.o = oracle
+        self.store = {}
 
-    @staticmethod
-    def _chunk(vol, W):
-        """[nzl][ny][nx] -> [W][nzl][ny/W][nx] (all-to-all send order)."""
-        nzl, ny, nx = vol.shape
-        return vol.reshape(nzl, W, ny // W, nx).permute(1, 0, 2, 3).contiguous()
+    def ck_bytes(self, slab_shape):
+        return 8
 
-    @staticmethod
-    def _unchunk(ch):
-        W, nzl, nyl, nx = ch.shape
-        return ch.permute(1, 0, 2, 3).contiguous().reshape(nzl, W * nyl, nx)
-
-    def prepare(self, img, mask, tc, cf, y_chunks):
+    def prepare(self, img, mask, tc, cf):
         if mask is None:
-            tc.copy_(self._chunk(img.float(), y_chunks).reshape(tc.shape))
+            tc.copy_(img.float())
         else:
-            tc.copy_(self._chunk(img.float() * mask.float(), y_chunks).reshape(tc.shape))
-            cf.copy_(self._chunk(mask.float(), y_chunks).reshape(cf.shape))
+            tc.copy_(img.float() * mask.float())
+            cf.copy_(mask.float())
 
-    def gaussian_axis_batch(self, srcs, dsts, spacing, axis, sigmas, in_y_chunks=1):
+    @staticmethod
+    def _views(buf, nf, nl):
+        a = buf.numpy()
+        y = a[: nf * nl * 48].reshape(nf, nl * 48)
+        ys = [y[k, : nl * 32].view(np.float64).reshape(4, nl) for k in range(nf)]
+        xs = [y[k, nl * 32:].view(np.float32).reshape(4, nl) for k in range(nf)]
+        return ys, xs
+
+    def z_sweep(self, direction, srcs, spacing, sigmas, line0, nlines, has_neighbour, state_in,
+                state_out, cks):
+        nf = len(srcs)
+        nzl, ny, nx = srcs[0].shape
+        yo, xo = self._views(state_out, nf, nlines)
+        if has_neighbour:
+            yi, xi = self._views(state_in, nf, nlines)
+        for k in range(nf):
+            c = self.o.gauss_coeffs(sigmas[k], spacing[2])
+            x = srcs[k].numpy().reshape(nzl, ny * nx)[:, line0:line0 + nlines].astype(np.float64)
+            out = np.empty_like(x)
+            if direction == 0:
+                N = (c.N0, c.N1, c.N2, c.N3)
+                D = (c.D1, c.D2, c.D3, c.D4)
+                B = (c.BN1, c.BN2, c.BN3, c.BN4)
+                if has_neighbour:
+                    yh = [yi[k][j].copy() for j in range(4)]          # y[i-1..i-4]
+                    xh = [xi[k][j].astype(np.float64) for j in range(3)]  # x[i-1..i-3]
+                else:
+                    yh = [x[0].copy() for _ in range(4)]
+                    xh = [x[0].copy() for _ in range(3)]
+                for i in range(nzl):
+                    a = x[i] * N[0] + xh[0] * N[1] + xh[1] * N[2] + xh[2] * N[3]
+                    d = [B[j] if (not has_neighbour and i <= j) else D[j] for j in range(4)]
+                    t = yh[0] * d[0] + yh[1] * d[1] + yh[2] * d[2] + yh[3] * d[3]
+                    y = a - t
+                    out[i] = y
+                    xh = [x[i], xh[0], xh[1]]
+                    yh = [y, yh[0], yh[1], yh[2]]
+                for j in range(4):
+                    yo[k][j] = yh[j]
+                for j in range(3):
+                    xo[k][j] = xh[j].astype(np.float32)
+                xo[k][3] = 0
+            else:
+                M = (c.M1, c.M2, c.M3, c.M4)
+                D = (c.D1, c.D2, c.D3, c.D4)
+                B = (c.BM1, c.BM2, c.BM3, c.BM4)
+                if has_neighbour:
+                    yh = [yi[k][j].copy() for j in range(4)]              # y[i+1..i+4]
+                    xh = [xi[k][j].astype(np.float64) for j in range(4)]  # x[i+1..i+4]
+                else:
+                    yh = [x[nzl - 1].copy() for _ in range(4)]
+                    xh = [x[nzl - 1].copy() for _ in range(4)]
+                for i in range(nzl - 1, -1, -1):
+                    a = xh[0] * M[0] + xh[1] * M[1] + xh[2] * M[2] + xh[3] * M[3]
+                    d = [B[j] if (not has_neighbour and i + j + 1 >= nzl) else D[j] for j in range(4)]
+                    t = yh[0] * d[0] + yh[1] * d[1] + yh[2] * d[2] + yh[3] * d[3]
+                    y = a - t
+                    out[i] = y
+                    xh = [x[i], xh[0], xh[1], xh[2]]
+                    yh = [y, yh[0], yh[1], yh[2]]
+                for j in range(4):
+                    yo[k][j] = yh[j]
+                    xo[k][j] = xh[j].astype(np.float32)
+            self.store[(cks[k].data_ptr(), direction, line0)] = out
+
+    def z_combine(self, srcs, dsts, spacing, sigmas, has_lo, has_hi, cks):
+        import torch
+        for k, dst in enumerate(dsts):
+            nzl, ny, nx = dst.shape
+            res = np.empty((nzl, ny * nx), np.float32)
+            for (ptr, d, l0), v in list(self.store.items()):
+                if ptr == cks[k].data_ptr() and d == 0:
+                    w = self.store[(ptr, 1, l0)]
+                    res[:, l0:l0 + v.shape[1]] = (v + w).astype(np.float32)
+            dst.copy_(torch.from_numpy(res.reshape(nzl, ny, nx)))
+
+    def gaussian_axis_batch(self, srcs, dsts, spacing, axis, sigmas):
         import torch
         for src, dst, sigma in zip(srcs, dsts, sigmas):
-            a = self._unchunk(src) if in_y_chunks > 1 else src.contiguous()
-            a = a.reshape(tuple(dst.shape))
             dst.copy_(torch.from_numpy(
-                self.o.recursive_gaussian_axis(a.numpy(), axis, sigma, spacing)))
+                self.o.recursive_gaussian_axis(src.contiguous().numpy(), axis, sigma, spacing)))
 
     def features(self, num, den, mask, slab_shape, spacing, halo_lo, halo_hi, out, layout):
         import torch
@@ -80,8 +154,9 @@ class OracleStages:
         out.copy_(torch.from_numpy(res))
 
 
-def _worker(rank, world, port, shape, sigmas, spacing, use_hip, ret):
+def _worker(rank, world, port, shape, sigmas, spacing, use_hip, bounds, line_groups, steps, ret):
     sys.path.insert(0, ROOT)
+    os.environ["IFE_TRIG_MODE"] = "0"
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -92,28 +167,39 @@ def _worker(rank, world, port, shape, sigmas, spacing, use_hip, ret):
         synth = importlib.import_module(PKG + ".synthetic")
         slab = importlib.import_module(PKG + ".slab")
         nz, ny, nx = shape
-        nzl = nz // world
-        img = synth.volume_f32((nzl, ny, nx), 77, z0=rank * nzl)
-        mask = np.minimum(synth.mask_ellipsoids((nzl, ny, nx), z0=rank * nzl, nz_total=nz), 1)
+        b = bounds or slab.slab_bounds(nz, world)
+        z0, nzl = b[rank], b[rank + 1] - b[rank]
+        img = synth.volume_f32((nzl, ny, nx), 77, z0=z0)
+        mask = np.minimum(synth.mask_ellipsoids((nzl, ny, nx), z0=z0, nz_total=nz), 1)
         mask = mask.astype(np.uint8)
         mask[:, :2, :] = 1
+        streams = None
         if use_hip:
             dev = torch.device("cuda", 0)
+            streams = slab._Streams(torch, dev, two_streams=True)
             ctx = pkg.Context(0)
-            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-            stages = slab.HipStages(pkg, ctx)
+            ctx.set_stream(streams.bulk.cuda_stream)
+            cctx = pkg.Context(0)
+            cctx.set_stream(streams.chain.cuda_stream)
+            stages = slab.HipStages(pkg, ctx, cctx)
             comm = slab.TorchComm(dist, rank, world, host_staging=True)
         else:
             from oracle import pyoracle
             pyoracle.set_threads(2)
             dev = torch.device("cpu")
             stages = OracleStages(pyoracle)
-            comm = slab.TorchComm(dist, rank, world, host_staging=True)
-        empty = lambda shp: torch.empty(shp, dtype=torch.float32, device=dev)
-        eng = slab.SlabEngine(stages, comm, shape, spacing, sigmas, rank, world, empty,
-                              pkg.INTERLEAVED, has_mask=True, overlap=False)
+            comm = slab.TorchComm(dist, rank, world, host_staging=False)  # the product branch
+        dt = {"float32": torch.float32, "uint8": torch.uint8}
+        alloc = lambda shp, d: torch.empty(shp, dtype=dt[d], device=dev)
+        eng = slab.SlabEngine(stages, comm, shape, spacing, sigmas, rank, world, alloc,
+                              pkg.INTERLEAVED, has_mask=True, bounds=bounds,
+                              line_groups=line_groups, streams=streams)
         out = torch.empty((len(sigmas), nzl, ny, nx, 8), dtype=torch.float32, device=dev)
-        eng.run(torch.from_numpy(img).to(dev), torch.from_numpy(mask).to(dev), out)
+        d_img, d_mask = torch.from_numpy(img).to(dev), torch.from_numpy(mask).to(dev)
+        for _ in range(steps):  # a second step reuses every buffer and pending send
+            out.zero_()
+            eng.run(d_img, d_mask, out)
+        eng.finish()
         if use_hip:
             torch.cuda.synchronize()
         np.save(os.path.join(ret, "out_%d.npy" % rank), out.cpu().numpy())
@@ -121,11 +207,12 @@ def _worker(rank, world, port, shape, sigmas, spacing, use_hip, ret):
         dist.destroy_process_group()
 
 
-def _run_world(world, shape, sigmas, spacing, use_hip, tmp_path):
+def _run_world(world, shape, sigmas, spacing, use_hip, tmp_path, bounds=None, line_groups=None,
+               steps=1):
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, shape, sigmas, spacing, use_hip, str(tmp_path)),
-             nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, shape, sigmas, spacing, use_hip, bounds, line_groups,
+                            steps, str(tmp_path)), nprocs=world, join=True)
     parts = [np.load(os.path.join(str(tmp_path), "out_%d.npy" % r)) for r in range(world)]
     return np.concatenate(parts, axis=1)  # along z
 
@@ -137,31 +224,102 @@ def _whole_volume(synth, shape):
     return img, mask
 
 
-@pytest.mark.parametrize("world,shape,spacing", [(2, (16, 128, 12), (1.0, 1.0, 1.0)),
-                                                 (4, (8, 256, 9), (0.8, 1.0, 1.25))])
-def test_slab_engine_equals_single_process_oracle(oracle, synth, tmp_path, world, shape, spacing):
-    sigmas = [1.0, 2.0]
-    got = _run_world(world, shape, sigmas, spacing, False, tmp_path)
+@pytest.mark.parametrize("world,shape,spacing,bounds,groups,steps", [
+    (2, (16, 20, 12), (1.0, 1.0, 1.0), None, 1, 2),
+    (3, (19, 40, 30), (1.0, 1.0, 1.0), [0, 4, 11, 19], 3, 1),     # uneven cut, 3 line groups
+    (4, (29, 24, 40), (0.8, 1.0, 1.25), None, 2, 2),               # 8,7,7,7 planes
+])
+def test_slab_engine_equals_single_process_oracle(oracle, synth, tmp_path, world, shape, spacing,
+                                                  bounds, groups, steps):
+    sigmas = [1.0, 2.0, 3.5]
+    got = _run_world(world, shape, sigmas, spacing, False, tmp_path, bounds, groups, steps)
     img, mask = _whole_volume(synth, shape)
     for s, sigma in enumerate(sigmas):
         ref = oracle.emphysema_features(img, mask, sigma, spacing)
         np.testing.assert_array_equal(got[s], ref)
 
 
-def test_slab_engine_rejects_uneven_cuts(ife):
+def test_sweep_schedule_is_consistent_between_neighbours(ife):
+    """The deadlock-freedom argument of slab.py: every event waits for an event with a
+    smaller key on the neighbour, and a rank runs its events in key order."""
+    slab = importlib.import_module(PKG + ".slab")
+    for W in (2, 3, 4, 8):
+        for n in (1, 3, 6):
+            order = [slab.sweep_schedule(r, W, n) for r in range(W)]
+            pos = [{e: k for k, e in enumerate(o)} for o in order]
+            done = [0] * W  # simulate: a rank advances when its head event's dependency is done
+            fin = [set() for _ in range(W)]
+            progressed = True
+            while progressed:
+                progressed = False
+                for r in range(W):
+                    while done[r] < len(order[r]):
+                        d, i = order[r][done[r]]
+                        nb = r - 1 if d == 0 else r + 1
+                        if 0 <= nb < W and (d, i) not in fin[nb]:
+                            break
+                        fin[r].add((d, i))
+                        done[r] += 1
+                        progressed = True
+            assert all(done[r] == 2 * n for r in range(W)), (W, n, done)
+            assert all(len(p) == 2 * n for p in pos)
+
+
+def test_slab_engine_rejects_thin_slabs(ife):
     slab = importlib.import_module(PKG + ".slab")
     with pytest.raises(ValueError):
-        slab.SlabEngine(None, None, (10, 12, 8), (1, 1, 1), [1.0], 0, 4, lambda s: None, 0)
-    with pytest.raises(ValueError):  # Y chunks must be wave aligned
-        slab.SlabEngine(None, None, (8, 64, 8), (1, 1, 1), [1.0], 0, 2, lambda s: None, 0)
+        slab.SlabEngine(None, None, (10, 12, 8), (1, 1, 1), [1.0], 0, 4, lambda s, d: None, 0)
+    with pytest.raises(ValueError):
+        slab.SlabEngine(None, None, (16, 12, 8), (1, 1, 1), [1.0], 0, 2, lambda s, d: None, 0,
+                        bounds=[0, 3, 16])
+    assert slab.slab_bounds(29, 4) == [0, 8, 15, 22, 29]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
-def test_slab_engine_on_gpu_equals_single_gpu(ife, synth, tmp_path, world):
-    shape, sigmas, spacing = (32, 256, 40), [1.0, 3.0], (1.0, 1.0, 1.0)
-    got = _run_world(world, shape, sigmas, spacing, True, tmp_path)
+@pytest.mark.parametrize("world,shape,groups", [(2, (128, 512, 512), 2), (4, (45, 96, 200), 3)])
+def test_slab_engine_on_gpu_equals_single_gpu(ife, synth, tmp_path, world, shape, groups):
+    """HIP stages, two streams per rank, ranks sharing the one GPU: bit-identical to the
+    single-GPU path (which is itself compared with the oracle elsewhere)."""
+    sigmas, spacing = [1.0, 3.0, 2.0], (1.0, 1.0, 1.0)
+    got = _run_world(world, shape, sigmas, spacing, True, tmp_path, None, groups, 2)
     img, mask = _whole_volume(synth, shape)
     with ife.Context(0) as c:
+        c.set_option(ife.OPT_TRIG_MODE, 0)
         ref = c.emphysema_features(img, mask, sigmas, spacing)
     np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_z_slab_stage_kernels_match_single_device_pass(ife, oracle, synth):
+    """The three slab kernels on their own: a volume cut into slabs of awkward sizes, states
+    handed over in host order, equals the oracle's Z pass bit for bit."""
+    import torch
+    shape, sigma, spacing = (61, 20, 70), 2.5, (1.0, 1.0, 0.8)
+    vol = synth.volume_f32(shape, 5)
+    ref = oracle.recursive_gaussian_axis(vol, 2, sigma, spacing)
+    nz, ny, nx = shape
+    L = ny * nx
+    for bounds in ([0, 61], [0, 4, 61], [0, 25, 30, 61], [0, 13, 26, 39, 61]):
+        W = len(bounds) - 1
+        ctx = ife.Context(0)
+        slabs = [torch.from_numpy(vol[bounds[r]:bounds[r + 1]].copy()).cuda() for r in range(W)]
+        outs = [torch.empty_like(s) for s in slabs]
+        cks = [torch.empty(ctx.stage_z_ck_bytes(tuple(s.shape)), dtype=torch.uint8, device="cuda")
+               for s in slabs]
+        up = [torch.zeros(48 * L, dtype=torch.uint8, device="cuda") for _ in range(W)]
+        dn = [torch.zeros(48 * L, dtype=torch.uint8, device="cuda") for _ in range(W)]
+        for r in range(W):
+            ctx.stage_z_sweep(0, [slabs[r].data_ptr()], tuple(slabs[r].shape), spacing, 0, L, [sigma],
+                              r > 0, up[r - 1].data_ptr() if r > 0 else None, up[r].data_ptr(),
+                              [cks[r].data_ptr()])
+        for r in range(W - 1, -1, -1):
+            ctx.stage_z_sweep(1, [slabs[r].data_ptr()], tuple(slabs[r].shape), spacing, 0, L, [sigma],
+                              r < W - 1, dn[r + 1].data_ptr() if r < W - 1 else None,
+                              dn[r].data_ptr(), [cks[r].data_ptr()])
+        for r in range(W):
+            ctx.stage_z_combine([slabs[r].data_ptr()], [outs[r].data_ptr()], tuple(slabs[r].shape),
+                                spacing, 0, L, [sigma], r > 0, r < W - 1, [cks[r].data_ptr()])
+        torch.cuda.synchronize()
+        got = np.concatenate([o.cpu().numpy() for o in outs], 0)
+        ctx.close()
+        np.testing.assert_array_equal(got, ref, err_msg=str(bounds))
