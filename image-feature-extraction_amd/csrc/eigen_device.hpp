@@ -332,6 +332,85 @@ __device__ __forceinline__ Eig3 eig3_sym_fast(float A11, float A12, float A13, f
   return r;
 }
 
+// Correctly rounded float square root for NORMAL x in [2^-100, 2^100]: the hardware root
+// (1 ulp) and the neighbour test hipcc's own sqrtf expansion uses, without that expansion's
+// scaling of tiny arguments and special-value fix-up (9 instead of 17 instructions).
+__device__ __forceinline__ float sqrt_rn_normal(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+  const float su = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+  const float ed = fmaf(-sd, s, x);
+  const float eu = fmaf(-su, s, x);
+  float r = ed <= 0.0f ? sd : s;
+  r = eu > 0.0f ? su : r;
+  return r;
+}
+// x / D without the range test of div_by_const (the caller has established
+// 2^-100 <= |x| <= 2^100 or x == 0)
+template <int D>
+__device__ __forceinline__ float div_by_const_inrange(float x) {
+  const float d = (float)D;
+  const float y = D == 3 ? 0x1.555556p-2f : 0x1.555556p-3f;
+  const float q = x * y;
+  const float f = fmaf(fmaf(-d, q, x), y, q);
+  return x == 0.0f ? x : f;
+}
+
+// The default solver (IFE_OPT_TRIG_MODE=2): eig3_sym_fast<2> with its range tests folded
+// into ONE rare branch.  q, p, B, r are the same bits as in every other mode.
+template <typename KT>
+__device__ __forceinline__ Eig3 eig3_sym_fast2(float A11, float A12, float A13, float A22,
+                                              float A23, float A33, const KT &K) {
+  const float p0 = A12 * A12 + A13 * A13 + A23 * A23;
+  const bool diag = p0 == 0.0f;
+  const float tr = A11 + A22 + A33;
+  const float q = div_by_const_inrange<3>(tr);
+  const float d1 = A11 - q, d2 = A22 - q, d3 = A33 - q;
+  const float p2 = d1 * d1 + d2 * d2 + d3 * d3 + 2.0f * p0;
+  const float atr = fabsf(tr);
+  // everything the short forms assume: |tr| and p2 of ordinary magnitude (then p lies in
+  // [2^-52, 2^49], inside the range of the shared reciprocal)
+  const bool ok = (atr <= 0x1p100f) && (atr >= 0x1p-100f || atr == 0.0f) && (p2 >= 0x1p-100f) &&
+                  (p2 <= 0x1p100f);
+  const bool unsafe = !diag && !ok;
+  const float p = sqrt_rn_normal(div_by_const_inrange<6>(p2));
+  const SharedRecip rp = shared_recip(p);
+  const float B11 = div_shared(d1, rp), B12 = div_shared(A12, rp), B13 = div_shared(A13, rp);
+  const float B22 = div_shared(d2, rp), B23 = div_shared(A23, rp), B33 = div_shared(d3, rp);
+  const float r2 = B11 * B22 * B33 + 2.0f * B12 * B13 * B23 - B23 * B23 * B11 -
+                   B13 * B13 * B22 - B12 * B12 * B33;
+  const float rr = r2 * 0.5f;
+  const float twop = 2.0f * p;
+  float phi = acos_third_f32(rr);
+  phi = rr >= 1.0f ? 0.0f : phi;
+  phi = rr <= -1.0f ? (float)(M_PI / 3) : phi;
+  float e0 = fmaf(twop, cos_small_f32(phi), q);
+  float e2 = fmaf(-twop, cos_small_f32((float)(M_PI / 3) - phi), q);
+  float e1 = 3.0f * q - e0 - e2;
+  if (fabsf(e0) < fabsf(e2)) { const float t = e0; e0 = e2; e2 = t; }
+  if (fabsf(e1) < fabsf(e2)) { const float t = e1; e1 = e2; e2 = t; }
+  Eig3 r;
+  r.e0 = e0; r.e1 = e1; r.e2 = e2;
+  if (__builtin_amdgcn_ballot_w64(diag || unsafe) != 0) {  // rare: one scalar branch
+    const float a1 = fabsf(A11), a2 = fabsf(A22), a3 = fabsf(A33);
+    const bool c12 = a1 > a2, c13 = a1 > a3, c23 = a2 > a3;
+    const float g0 = c12 ? (c13 ? A11 : A33) : (c23 ? A22 : A33);
+    const float g1 = c12 ? (c13 ? (c23 ? A22 : A33) : A11) : (c23 ? (c13 ? A11 : A33) : A22);
+    const float g2 = c12 ? (c13 ? (c23 ? A33 : A22) : A22) : (c23 ? (c13 ? A33 : A11) : A11);
+    r.e0 = diag ? g0 : r.e0;
+    r.e1 = diag ? g1 : r.e1;
+    r.e2 = diag ? g2 : r.e2;
+    if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {
+      // out of line and exact (double libm): the rare lanes need not be fast
+      const Eig3 g = eig3_sym_generic_call<0>(A11, A12, A13, A22, A23, A33);
+      r.e0 = unsafe ? g.e0 : r.e0;
+      r.e1 = unsafe ? g.e1 : r.e1;
+      r.e2 = unsafe ? g.e2 : r.e2;
+    }
+  }
+  return r;
+}
+
 struct EigFeat {
   float f[6];
 };
@@ -340,7 +419,9 @@ struct EigFeat {
 template <int TRIG, typename KT = EigConstImm>
 __device__ __forceinline__ EigFeat eig_features(float A11, float A12, float A13, float A22,
                                                 float A23, float A33, const KT &K = KT()) {
-  const Eig3 ev = eig3_sym_fast<TRIG>(A11, A12, A13, A22, A23, A33, K);
+  Eig3 ev;
+  if constexpr (TRIG == 2) ev = eig3_sym_fast2(A11, A12, A13, A22, A23, A33, K);
+  else ev = eig3_sym_fast<TRIG>(A11, A12, A13, A22, A23, A33, K);
   EigFeat o;
   o.f[0] = ev.e0;
   o.f[1] = ev.e1;

@@ -158,11 +158,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef IFE_FT_KLDS
 #define IFE_FT_KLDS 1  // 1: solver constants from LDS, 0: immediates
 #endif
+// Waves per SIMD the register allocation aims at.  The default solver (TRIG 2) fits three
+// 512-thread workgroups per CU (6 waves per SIMD, 80 VGPRs: measured 1.39 -> 1.30 ms per launch);
+// the double-precision solvers and the general-spacing forms need more registers.
 #ifndef IFE_FT_WAVES
-#define IFE_FT_WAVES 1
+#define IFE_FT_WAVES(MODE, UNIT, TRIG) ((TRIG) == 2 && (UNIT) ? 6 : 1)
 #endif
 template <int MODE, bool UNIT, int TRIG, bool PLANAR, typename VAL, typename TM>
-__global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL val, const TM *__restrict__ mask,
+__global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES(MODE, UNIT, TRIG)) void features_kernel(VAL val, const TM *__restrict__ mask,
                                                               float *__restrict__ out, FeatGeom g,
                                                               DerivCoef dc) {
   __shared__ float tile[4][FT_HY][FT_HX];
@@ -354,7 +357,11 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
         double a = gx * gx;
         a += gy * gy;
         a += gz * gz;
+#if defined(IFE_DIAG_NO_GSQRT)
+        G = (float)a;
+#else
         G = (float)sqrt(a);
+#endif
       }
       if constexpr (MODE == FEAT_GRADMAG) {
         o[0] = G;
@@ -396,10 +403,14 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES) void features_kernel(VAL 
           o[0] = dxx; o[1] = dxy; o[2] = dxz; o[3] = dyy; o[4] = dyz; o[5] = dzz;
         } else {
           EigFeat ef;
+#if defined(IFE_DIAG_NO_SOLVER)  // timing diagnostics only: results are wrong by construction
+          ef.f[0] = dxx; ef.f[1] = dxy; ef.f[2] = dxz; ef.f[3] = dyy; ef.f[4] = dyz; ef.f[5] = dzz;
+#else
           if constexpr (KLDS)
             ef = eig_features<TRIG>(dxx, dxy, dxz, dyy, dyz, dzz, EigConstLds::at(ktab));
           else
             ef = eig_features<TRIG>(dxx, dxy, dxz, dyy, dyz, dzz);
+#endif
           if constexpr (F8) {
             o[0] = c; o[1] = G;
 #pragma unroll
@@ -463,7 +474,7 @@ __global__ __launch_bounds__(256) void eig_batch_kernel(const float *__restrict_
   if (NOUT == 3) {
     Eig3 e = trig == 0   ? eig3_sym_fast<0>(a[0], a[1], a[2], a[3], a[4], a[5], EigConstImm())
              : trig == 1 ? eig3_sym_fast<1>(a[0], a[1], a[2], a[3], a[4], a[5], EigConstImm())
-                         : eig3_sym_fast<2>(a[0], a[1], a[2], a[3], a[4], a[5], EigConstImm());
+                         : eig3_sym_fast2(a[0], a[1], a[2], a[3], a[4], a[5], EigConstImm());
     outv[i * 3 + 0] = e.e0; outv[i * 3 + 1] = e.e1; outv[i * 3 + 2] = e.e2;
   } else {
     EigFeat f = trig == 0   ? eig_features<0>(a[0], a[1], a[2], a[3], a[4], a[5])

@@ -28,6 +28,7 @@ def dev(ife, big):
          "out_b": torch.empty((N, N, N, 8), dtype=torch.float32, device="cuda")}
     c = ife.Context(0)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.set_option(ife.OPT_TRIG_MODE, 0)  # the tests below that use another mode say so
     d["ctx"] = c
     yield d
     c.close()
@@ -65,6 +66,41 @@ def test_full_size_matches_oracle(ife, oracle, big, dev):
           % (worst, exact))
     assert worst <= 1e-6
     assert (got[mask == 0] == 0).all()
+
+
+def test_bench_workload_matches_oracle_at_full_size(ife, oracle, big, dev):
+    """bench.py's exact workload -- 512^3, explicit ALL-ONES uint8 mask (the per-wave
+    "certainty == 1: skip the divide" path), sigma = 1, 2, 4 -- whole volume against the
+    oracle (ImageToEmphysemaFeaturesFilter.hxx:99-121).  Smoothed value and gradient
+    magnitude bit exact at every voxel; eigen features by MAXIMUM error relative to
+    |lambda_1| (printed): <= 1e-6 in the double mode, <= 2e-6 in the library's default float
+    mode, whose north_star bar is 1e-5."""
+    import torch
+    from oracle.parity import assert_eig_parity
+    img, _ = big
+    ones = np.ones((N, N, N), np.uint8)
+    d_ones = torch.from_numpy(ones).cuda()
+    oracle.set_threads(min(16, os.cpu_count() or 1))
+    ctx = dev["ctx"]
+    for sigma in (1.0, 2.0, 4.0):
+        ref = oracle.emphysema_features(img, ones, sigma)
+        for mode, tol in ((2, 2e-6), (0, 1e-6)):
+            ctx.set_option(ife.OPT_TRIG_MODE, mode)
+            try:
+                run(ife, dev, dev["img"], d_ones, sigma, dev["out_a"])
+            finally:
+                ctx.set_option(ife.OPT_TRIG_MODE, 0)
+            got = dev["out_a"].cpu().numpy()
+            assert np.array_equal(got[..., 0], ref[..., 0]), "smoothed value, sigma %g" % sigma
+            assert np.array_equal(got[..., 1], ref[..., 1]), "gradient magnitude, sigma %g" % sigma
+            p = assert_eig_parity(got, ref, tol, "sigma %g mode %d" % (sigma, mode))
+            print("512^3 all-ones sigma %g trig mode %d: max eigenvalue error %.3g |lambda1| "
+                  "(sum %.3g, Frobenius %.3g, product %.3g |lambda1|^3), %d of %d triples in "
+                  "another order" % (sigma, mode, p["max_err"], p["max_err_sum"], p["max_err_frob"],
+                                     p["max_err_prod"], p["order_diff"], p["n"]))
+            del got
+        del ref
+    del d_ones
 
 
 def test_power_of_two_scaling_is_exact_at_full_size(ife, dev):
