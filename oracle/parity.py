@@ -19,14 +19,17 @@ def eig_parity(got, ref, block=1 << 22):
       max_err      max over voxels of |sorted(got) - sorted(ref)|_inf / |lambda_1|
       max_err_sum, max_err_frob  (/|lambda_1|), max_err_prod (/|lambda_1|^3)  when C >= 6
       order_diff   number of voxels whose triple is the same set in another order
-      mag_ordered  every got triple satisfies |e0| >= |e1| >= |e2|
+      mag_slack    max over voxels of (|e1| - |e0|, |e2| - |e1|, 0) / |lambda_1| of the device
+                   triple: 0 when it is magnitude-ordered.  The reference's own order is only
+                   as good as its float rounding (e1 = 3q - e0 - e2 can pass a nearly equal e0
+                   by an ulp after the :123-129 swaps), so this is a tolerance, not an identity
       n            voxels compared (finite reference)
     """
     C = got.shape[-1]
     e0 = C - 6 if C >= 6 else 0
     g2 = got.reshape(-1, C)
     r2 = ref.reshape(-1, C)
-    out = {"max_err": 0.0, "order_diff": 0, "mag_ordered": True, "n": 0,
+    out = {"max_err": 0.0, "order_diff": 0, "mag_slack": 0.0, "n": 0,
            "max_err_sum": 0.0, "max_err_frob": 0.0, "max_err_prod": 0.0}
     for i in range(0, g2.shape[0], block):
         g = g2[i:i + block, e0:].astype(np.float64)
@@ -46,7 +49,8 @@ def eig_parity(got, ref, block=1 << 22):
         out["max_err"] = max(out["max_err"], float(se.max()))
         out["order_diff"] += int((de > se).sum())
         a = np.abs(g[:, :3])
-        out["mag_ordered"] &= bool(((a[:, 0] >= a[:, 1]) & (a[:, 1] >= a[:, 2])).all())
+        slack = np.maximum(np.maximum(a[:, 1] - a[:, 0], a[:, 2] - a[:, 1]), 0.0) / lam
+        out["mag_slack"] = max(out["mag_slack"], float(slack.max()))
         out["n"] += g.shape[0]
         if g.shape[1] >= 6:
             out["max_err_sum"] = max(out["max_err_sum"], float((np.abs(g[:, 3] - r[:, 3]) / lam).max()))
@@ -60,7 +64,7 @@ def assert_eig_parity(got, ref, tol, what="", max_order_frac=1e-4):
     """Assert the north_star style bar `tol` (relative to |lambda_1|) on triples and derived
     scalars; returns the measurement dict for reporting."""
     p = eig_parity(got, ref)
-    assert p["mag_ordered"], "%s: device triple is not magnitude-ordered" % what
+    assert p["mag_slack"] <= tol, "%s: device triple out of magnitude order by %.3g" % (what, p["mag_slack"])
     assert p["max_err"] <= tol, "%s: eigenvalue error %.3g > %.3g" % (what, p["max_err"], tol)
     if got.shape[-1] >= 6:
         assert p["max_err_sum"] <= 2 * tol, "%s: sum error %.3g" % (what, p["max_err_sum"])

@@ -96,8 +96,9 @@ def test_bench_workload_matches_oracle_at_full_size(ife, oracle, big, dev):
             p = assert_eig_parity(got, ref, tol, "sigma %g mode %d" % (sigma, mode))
             print("512^3 all-ones sigma %g trig mode %d: max eigenvalue error %.3g |lambda1| "
                   "(sum %.3g, Frobenius %.3g, product %.3g |lambda1|^3), %d of %d triples in "
-                  "another order" % (sigma, mode, p["max_err"], p["max_err_sum"], p["max_err_frob"],
-                                     p["max_err_prod"], p["order_diff"], p["n"]))
+                  "another order, magnitude-order slack %.3g"
+                  % (sigma, mode, p["max_err"], p["max_err_sum"], p["max_err_frob"],
+                     p["max_err_prod"], p["order_diff"], p["n"], p["mag_slack"]))
             del got
         del ref
     del d_ones
