@@ -93,6 +93,14 @@ struct ValSmooth {
     return r.b != 0.0f ? r.a / r.b : FLT_MAX;
   }
 };
+// The smoothed field itself (the last axis pass has divided already, or the certainty is
+// identically one): one float per voxel and no run-time choice inside the kernel.
+struct ValS {
+  const float *s;
+  struct Raw { float a; };
+  __device__ __forceinline__ Raw fetch(int64_t i) const { return Raw{s[i]}; }
+  __device__ __forceinline__ float finish(const Raw &r) const { return r.a; }
+};
 template <typename TI>
 struct ValRaw {
   const TI *img;

@@ -509,6 +509,13 @@ int launch_features(ife_ctx *ctx, VAL val, const TM *mask, float *out,
                     const ife_volume_desc *v, int layout, int halo_lo = 0, int halo_hi = 0,
                     const uint32_t *seg_base = nullptr, int64_t col_stride = 0,
                     int64_t col_offset = 0) {
+  if constexpr (std::is_same<VAL, ValSmooth>::value) {
+    // no denominator (certainty identically one): the single-field source, a kernel without
+    // the run-time choice (measured 1.39 -> 1.23 ms per launch at 512^3)
+    if (val.den == nullptr)
+      return launch_features<MODE>(ctx, ValS{val.num}, mask, out, v, layout, halo_lo, halo_hi,
+                                   seg_base, col_stride, col_offset);
+  }
   FeatGeom g;
   g.seg_base = seg_base;
   g.col_offset = col_offset;

@@ -227,6 +227,20 @@ def test_emphysema_null_mask_equals_ones_mask(ctx, synth):
     np.testing.assert_array_equal(a, b)
 
 
+def test_normalized_convolution_where_the_certainty_vanishes(ctx, oracle, synth):
+    """Half of the volume without certainty: the smoothed denominator underflows to exactly
+    zero far from the support (Div functor -> FLT_MAX) and is tiny but non-zero near it."""
+    shape = (9, 70, 66)
+    img = synth.volume_f32(shape, 21)
+    cert = (synth.mask_ellipsoids(shape) > 0).astype(np.float32)
+    cert[:, : shape[1] // 2, :] = 0.0
+    cert += np.float32(0.25) * (np.arange(cert.size).reshape(shape) % 3 == 0) * (cert > 0)
+    got = ctx.normalized_gaussian_convolution(img, cert, 0.7)
+    ref = oracle.normalized_gaussian_convolution(img, cert, 0.7)
+    np.testing.assert_array_equal(got, ref)
+    assert (ref == np.finfo(np.float32).max).any()
+
+
 def test_emphysema_chunking_is_invisible(ctx, ife, synth):
     shape = (50, 20, 70)
     img = synth.volume_f32(shape, 12)
