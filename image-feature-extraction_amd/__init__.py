@@ -36,6 +36,7 @@ EXPORTS = (
     "ife_ctx_set_stream", "ife_ctx_set_option", "ife_ctx_reserve", "ife_ctx_synchronize",
     "ife_eigenvalues", "ife_eigenvalue_features", "ife_hessian3d", "ife_gradient_magnitude",
     "ife_normalized_gaussian_convolution", "ife_emphysema_features",
+    "ife_emphysema_features_begin", "ife_emphysema_features_fetch", "ife_emphysema_features_end",
     "ife_fd_hessian_features", "ife_fd_gradient_features", "ife_mask_image_f64",
     "ife_get_kernel_times", "ife_reset_kernel_times",
     "ife_stage_prepare", "ife_stage_recursive_gaussian", "ife_stage_recursive_gaussian_batch",
@@ -102,6 +103,9 @@ def load_library():
     lib.ife_normalized_gaussian_convolution.argtypes = [vp, f32p, f32p, vd, C.c_double, f32p, i32]
     lib.ife_emphysema_features.argtypes = [vp, vp, i32, vp, i32, vd, C.POINTER(C.c_float), i32,
                                            f32p, i32, i32]
+    lib.ife_emphysema_features_begin.argtypes = [vp, vp, i32, vp, i32, vd, C.POINTER(C.c_float), i32, i32]
+    lib.ife_emphysema_features_fetch.argtypes = [vp, i32, f32p]
+    lib.ife_emphysema_features_end.argtypes = [vp]
     lib.ife_fd_hessian_features.argtypes = [vp, vp, i32, vp, i32, vd, f32p, i32, i32]
     lib.ife_fd_gradient_features.argtypes = [vp, f32p, f32p, vd, f32p, i32]
     lib.ife_mask_image_f64.argtypes = [vp, vp, vp, C.c_double, i64, vp, i32]
@@ -270,6 +274,30 @@ class Context:
             self._h, image.ctypes.data, _IMG_DT[image.dtype], mptr, mdt, C.byref(d), sig,
             len(sigmas), out.ctypes.data, layout, MEM_HOST))
         return out
+
+    def emphysema_features_stream(self, image, mask, sigmas, spacing=(1.0, 1.0, 1.0),
+                                  layout=INTERLEAVED):
+        """Generator over the scales: begin once, yield one 8-component volume per sigma."""
+        image = np.ascontiguousarray(image)
+        if image.dtype not in _IMG_DT:
+            image = image.astype(np.float32)
+        mdt, mptr = U8, None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask)
+            mdt, mptr = _MSK_DT[mask.dtype], mask.ctypes.data
+        d = _desc(image.shape, spacing)
+        sig = (C.c_float * len(sigmas))(*[float(s) for s in sigmas])
+        self._chk(self._lib.ife_emphysema_features_begin(
+            self._h, image.ctypes.data, _IMG_DT[image.dtype], mptr, mdt, C.byref(d), sig,
+            len(sigmas), layout))
+        try:
+            shp = image.shape + (8,) if layout == INTERLEAVED else (8,) + image.shape
+            for k in range(len(sigmas)):
+                out = np.empty(shp, np.float32)
+                self._chk(self._lib.ife_emphysema_features_fetch(self._h, k, out.ctypes.data))
+                yield out
+        finally:
+            self._chk(self._lib.ife_emphysema_features_end(self._h))
 
     def fd_hessian_features(self, image, mask=None, spacing=(1.0, 1.0, 1.0), layout=INTERLEAVED):
         image = np.ascontiguousarray(image)

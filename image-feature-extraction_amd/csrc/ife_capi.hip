@@ -90,6 +90,12 @@ struct ife_ctx {
   DevBuf pre[2];  // image*certainty and certainty as float (prepass, shared by all scales)
   DevBuf ck_y[IIR_MAX_JOBS], ck_x[IIR_MAX_JOBS];  // one checkpoint area per concurrent job
   DevBuf st_img, st_mask, st_aux, st_out;  // HOST-mode staging
+  // streaming form of the scale loop (ife_emphysema_features_begin / _fetch / _end)
+  DevBuf sc_out;                     // all scales, device resident
+  std::vector<hipEvent_t> sc_done;   // one per scale: its feature launch has finished
+  hipStream_t sc_copy = nullptr;     // device-to-host copies beside the kernels of later scales
+  size_t sc_scale_bytes = 0;
+  std::vector<hipEvent_t> *scale_events = nullptr;  // emphysema_typed records into this when set
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
   double acc_ms[KK_COUNT] = {0};
@@ -662,6 +668,12 @@ static int emphysema_typed(ife_ctx *ctx, const TI *img, const TM *msk, const ife
       else
         rc = launch_features<FEAT_FEATURES8>(ctx, vs, msk, dout + (size_t)(s0 + k) * n * IFE_NUM_FEATURES, vol,
                                              layout);
+      if (!rc && ctx->scale_events) {
+        hipEvent_t e;
+        IFE_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->scale_events->push_back(e);
+        IFE_HIP(ctx, hipEventRecord(e, ctx->stream));
+      }
     }
     if (rc) return rc;
   }
@@ -704,8 +716,10 @@ void ife_ctx_destroy(ife_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  for (auto e : ctx->sc_done) (void)hipEventDestroy(e);
+  if (ctx->sc_copy) (void)hipStreamDestroy(ctx->sc_copy);
   std::vector<DevBuf *> bufs = {&ctx->pre[0], &ctx->pre[1], &ctx->st_img, &ctx->st_mask,
-                                &ctx->st_aux, &ctx->st_out};
+                                &ctx->st_aux, &ctx->st_out, &ctx->sc_out};
   for (auto &sl : ctx->fld)
     for (auto &b : sl) bufs.push_back(&b);
   for (auto &b : ctx->ck_y) bufs.push_back(&b);
@@ -910,6 +924,76 @@ int ife_emphysema_features(ife_ctx *ctx, const void *image, int image_dtype, con
   }
   if (rc) return rc;
   return stage_out_end(ctx, mem, out, out_bytes);
+}
+
+// ---- a9, streaming form -------------------------------------------------------------
+int ife_emphysema_features_end(ife_ctx *ctx) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  IFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->sc_copy) IFE_HIP(ctx, hipStreamSynchronize(ctx->sc_copy));
+  for (auto e : ctx->sc_done) (void)hipEventDestroy(e);
+  ctx->sc_done.clear();
+  if (ctx->sc_out.p) {
+    IFE_HIP(ctx, hipFree(ctx->sc_out.p));
+    ctx->sc_out.p = nullptr;
+    ctx->sc_out.cap = 0;
+  }
+  ctx->sc_scale_bytes = 0;
+  return IFE_OK;
+}
+
+int ife_emphysema_features_begin(ife_ctx *ctx, const void *image, int image_dtype, const void *mask,
+                                 int mask_dtype, const ife_volume_desc *vol, const float *sigmas,
+                                 int n_sigmas, int layout) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_vol(ctx, vol, true))) return rc;
+  if ((rc = check_layout_mem(ctx, layout, IFE_MEM_HOST))) return rc;
+  if (!image || !sigmas) return fail(ctx, IFE_E_ARG, "null pointer");
+  if (n_sigmas < 1) return fail(ctx, IFE_E_ARG, "at least one sigma is required");
+  for (int s = 0; s < n_sigmas; ++s)
+    if (!(sigmas[s] > 0.0f)) return fail(ctx, IFE_E_ARG, "sigma[%d] must be positive", s);
+  if (image_dtype != IFE_F32 && image_dtype != IFE_I16)
+    return fail(ctx, IFE_E_ARG, "image dtype must be IFE_F32 or IFE_I16");
+  if (mask && mask_dtype != IFE_U8 && mask_dtype != IFE_U16)
+    return fail(ctx, IFE_E_ARG, "mask dtype must be IFE_U8 or IFE_U16");
+  if ((rc = ife_emphysema_features_end(ctx))) return rc;  // drop an earlier, unfinished run
+  if ((rc = ife_ctx_reserve(ctx, vol))) return rc;
+  const size_t n = (size_t)(vol->nx * vol->ny * vol->nz);
+  ctx->sc_scale_bytes = n * IFE_NUM_FEATURES * sizeof(float);
+  if ((rc = ensure(ctx, ctx->sc_out, ctx->sc_scale_bytes * (size_t)n_sigmas))) return rc;
+  if (!ctx->sc_copy) IFE_HIP(ctx, hipStreamCreateWithFlags(&ctx->sc_copy, hipStreamNonBlocking));
+  const void *dI, *dM;
+  if ((rc = stage_in(ctx, IFE_MEM_HOST, image, n * dtype_size(image_dtype), ctx->st_img, &dI))) return rc;
+  if ((rc = stage_in(ctx, IFE_MEM_HOST, mask, n * (mask ? dtype_size(mask_dtype) : 0), ctx->st_mask, &dM)))
+    return rc;
+  float *dout = (float *)ctx->sc_out.p;
+  const bool u16 = mask && mask_dtype == IFE_U16;
+  ctx->scale_events = &ctx->sc_done;
+  if (image_dtype == IFE_F32)
+    rc = u16 ? emphysema_typed(ctx, (const float *)dI, (const uint16_t *)dM, vol, sigmas, n_sigmas, dout, layout)
+             : emphysema_typed(ctx, (const float *)dI, (const uint8_t *)dM, vol, sigmas, n_sigmas, dout, layout);
+  else
+    rc = u16 ? emphysema_typed(ctx, (const int16_t *)dI, (const uint16_t *)dM, vol, sigmas, n_sigmas, dout, layout)
+             : emphysema_typed(ctx, (const int16_t *)dI, (const uint8_t *)dM, vol, sigmas, n_sigmas, dout, layout);
+  ctx->scale_events = nullptr;
+  if (rc) (void)ife_emphysema_features_end(ctx);
+  return rc;
+}
+
+int ife_emphysema_features_fetch(ife_ctx *ctx, int scale, float *out) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if (!out) return fail(ctx, IFE_E_ARG, "null pointer");
+  if (scale < 0 || scale >= (int)ctx->sc_done.size())
+    return fail(ctx, IFE_E_STATE, "scale %d was not started by ife_emphysema_features_begin (%d scales)",
+                scale, (int)ctx->sc_done.size());
+  IFE_HIP(ctx, hipStreamWaitEvent(ctx->sc_copy, ctx->sc_done[scale], 0));
+  IFE_HIP(ctx, hipMemcpyAsync(out, (const char *)ctx->sc_out.p + (size_t)scale * ctx->sc_scale_bytes,
+                              ctx->sc_scale_bytes, hipMemcpyDeviceToHost, ctx->sc_copy));
+  IFE_HIP(ctx, hipStreamSynchronize(ctx->sc_copy));
+  return IFE_OK;
 }
 
 // ---- a6 -----------------------------------------------------------------------------

@@ -10,8 +10,16 @@
 // As with ITK's MTime logic, Update() re-executes only after an input or sigma changed, so
 // the eight Update() calls per scale of tools/ExtractFeatures.cxx:135-143 cost one
 // execution.
+//
+// One addition to the reference's interface: SetScales(all sigmas the caller is about to
+// visit).  With that hint the first Update() uploads image and mask once, runs Cast +
+// Multiply once and enqueues every scale on the device (ife_emphysema_features_begin); each
+// Update() then only fetches its scale, so writing scale k overlaps the device work of the
+// later ones.  Without the hint every scale is one self-contained call, as in the reference.
 #ifndef __ImageToEmphysemaFeaturesFilter_h
 #define __ImageToEmphysemaFeaturesFilter_h
+
+#include <vector>
 
 #include "ife/Host/Engine.h"
 
@@ -28,9 +36,15 @@ class ImageToEmphysemaFeaturesFilter {
   typedef PixelType ScalarRealType;  // .h:41
   ifeNewMacro(Self);
 
-  void SetInputImage(const InputImageType *image) { image_ = image; dirty_ = true; }
-  void SetInputMask(const InputMaskType *mask) { mask_ = mask; dirty_ = true; }
+  void SetInputImage(const InputImageType *image) { EndStream(); image_ = image; dirty_ = true; }
+  void SetInputMask(const InputMaskType *mask) { EndStream(); mask_ = mask; dirty_ = true; }
+  ~ImageToEmphysemaFeaturesFilter() { EndStream(); }
   void SetSigma(ScalarRealType s) { if (s != sigma_) { sigma_ = s; dirty_ = true; } }
+  void SetScales(const std::vector<ScalarRealType> &scales) {
+    EndStream();
+    scales_.assign(scales.begin(), scales.end());
+    dirty_ = true;
+  }
   ScalarRealType GetSigma() const { return sigma_; }
   static const size_t numFeatures = 8;  // .h:62
 
@@ -46,6 +60,24 @@ class ImageToEmphysemaFeaturesFilter {
     out_->CopyInformation(image_);
     out_->SetNumberOfComponentsPerPixel(numFeatures);  // .hxx:83-90
     out_->Allocate();
+    int which = -1;
+    for (size_t k = 0; k < scales_.size(); ++k)
+      if (scales_[k] == (float)sigma_) { which = (int)k; break; }
+    if (which >= 0) {  // the announced schedule: everything is started once, fetched per scale
+      if (!streaming_) {
+        e.check(ife_emphysema_features_begin(
+                    e.ctx(), image_->GetBufferPointer(), ife::host::ImageDType<PixelType>::value,
+                    mask_->GetBufferPointer(),
+                    ife::host::MaskDType<typename InputMaskType::PixelType>::value, &d,
+                    scales_.data(), (int)scales_.size(), IFE_INTERLEAVED),
+                "ImageToEmphysemaFeaturesFilter");
+        streaming_ = true;
+      }
+      e.check(ife_emphysema_features_fetch(e.ctx(), which, out_->GetBufferPointer()),
+              "ImageToEmphysemaFeaturesFilter");
+      dirty_ = false;
+      return;
+    }
     const float sig = (float)sigma_;
     e.check(ife_emphysema_features(
                 e.ctx(), image_->GetBufferPointer(), ife::host::ImageDType<PixelType>::value,
@@ -62,6 +94,14 @@ class ImageToEmphysemaFeaturesFilter {
   }
 
  private:
+  void EndStream() {
+    if (streaming_) {
+      (void)ife_emphysema_features_end(ife::host::Engine::Instance().ctx());
+      streaming_ = false;
+    }
+  }
+  std::vector<float> scales_;
+  bool streaming_ = false;
   const InputImageType *image_ = nullptr;
   const InputMaskType *mask_ = nullptr;
   ScalarRealType sigma_ = 1.0;  // .hxx:18

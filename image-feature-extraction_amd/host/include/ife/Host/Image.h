@@ -98,6 +98,23 @@ inline std::ostream &operator<<(std::ostream &os, const Region3 &r) {
   return os << "ImageRegion Index: " << r.index << " Size: " << r.size;
 }
 
+// World geometry of the file an image was read from, carried through untouched and written
+// back as it was: the arithmetic of the hot path uses the spacing only (the reference ignores
+// direction cosines too, Hessian3DImageFilter.hxx), but an output volume has to overlay its
+// source in any NIfTI / MetaImage aware consumer.  NIfTI: qform/sform codes, quaternion,
+// offsets, qfac and the three srow vectors; MetaImage: the TransformMatrix and
+// CenterOfRotation lines.  What ITK's own writer would derive from its direction matrix for a
+// file produced by OTHER software is not reproduced ("parity unpinned": no ITK here).
+struct FileGeometry {
+  bool has_nifti = false;
+  int16_t qform_code = 0, sform_code = 0;
+  float qfac = 1.0f, quatern[3] = {0, 0, 0}, qoffset[3] = {0, 0, 0};
+  float srow[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  char xyzt_units = 2;
+  bool has_mhd = false;
+  std::string mhd_transform, mhd_center, mhd_orientation;
+};
+
 class ImageBase3 {
  public:
   typedef Size3 SizeType;
@@ -111,15 +128,19 @@ class ImageBase3 {
   const Spacing3 &GetSpacing() const { return spacing_; }
   void SetOrigin(const Spacing3 &o) { origin_ = o; }
   const Spacing3 &GetOrigin() const { return origin_; }
+  void SetFileGeometry(const FileGeometry &g) { geom_ = g; }
+  const FileGeometry &GetFileGeometry() const { return geom_; }
   void CopyInformation(const ImageBase3 *o) {
     region_ = o->region_;
     spacing_ = o->spacing_;
     origin_ = o->origin_;
+    geom_ = o->geom_;
   }
 
  protected:
   Region3 region_;
   Spacing3 spacing_, origin_;
+  FileGeometry geom_;
 };
 
 template <typename TPixel, unsigned int VDim = 3>

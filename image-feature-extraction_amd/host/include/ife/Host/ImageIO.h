@@ -25,6 +25,7 @@ inline bool ends_with(const std::string &s, const std::string &suf) {
 struct RawVolume {
   Size3 size;
   Spacing3 spacing, origin;
+  FileGeometry geom;
   int nifti_type = 16;  // NIfTI datatype code of `bytes`
   double slope = 0.0, inter = 0.0;
   std::vector<unsigned char> bytes;
@@ -108,17 +109,31 @@ inline RawVolume read_nifti(const std::string &path) {
     throw ExceptionObject(path + " is not a 3-D scalar volume", "ImageFileReader");
   RawVolume v;
   for (int a = 0; a < 3; ++a) {
+    if (h.dim[1 + a] < 1) throw ExceptionObject(path + ": non-positive dimension in the header", "ImageFileReader");
     v.size[a] = (uint64_t)h.dim[1 + a];
-    v.spacing[a] = h.pixdim[1 + a] > 0 ? (double)h.pixdim[1 + a] : 1.0;
+    v.spacing[a] = (h.pixdim[1 + a] > 0 && std::isfinite(h.pixdim[1 + a])) ? (double)h.pixdim[1 + a] : 1.0;
   }
   v.origin[0] = h.qoffset_x; v.origin[1] = h.qoffset_y; v.origin[2] = h.qoffset_z;
+  v.geom.has_nifti = true;
+  v.geom.qform_code = h.qform_code; v.geom.sform_code = h.sform_code;
+  v.geom.qfac = h.pixdim[0];
+  v.geom.quatern[0] = h.quatern_b; v.geom.quatern[1] = h.quatern_c; v.geom.quatern[2] = h.quatern_d;
+  v.geom.qoffset[0] = h.qoffset_x; v.geom.qoffset[1] = h.qoffset_y; v.geom.qoffset[2] = h.qoffset_z;
+  std::memcpy(v.geom.srow[0], h.srow_x, sizeof h.srow_x);
+  std::memcpy(v.geom.srow[1], h.srow_y, sizeof h.srow_y);
+  std::memcpy(v.geom.srow[2], h.srow_z, sizeof h.srow_z);
+  v.geom.xyzt_units = h.xyzt_units;
   v.nifti_type = h.datatype;
   v.slope = h.scl_slope;
   v.inter = h.scl_inter;
   const size_t es = nifti_type_size(h.datatype);
   if (!es) throw ExceptionObject(path + ": unsupported NIfTI datatype", "ImageFileReader");
+  // dim[] are int16 (<= 32767 each), so the byte count fits 64 bits; vox_offset is a float
+  // from an untrusted file: it must be finite and inside the file before it becomes a size_t
+  if (!std::isfinite(h.vox_offset) || h.vox_offset < 352.0f || (double)h.vox_offset > (double)all.size())
+    throw ExceptionObject(path + ": bad vox_offset in the header", "ImageFileReader");
   const size_t off = (size_t)h.vox_offset, nb = (size_t)(v.size[0] * v.size[1] * v.size[2]) * es;
-  if (off < 352 || all.size() < off + nb)
+  if (all.size() - off < nb)
     throw ExceptionObject(path + ": truncated voxel data", "ImageFileReader");
   v.bytes.assign(all.begin() + (std::ptrdiff_t)off, all.begin() + (std::ptrdiff_t)(off + nb));
   return v;
@@ -145,6 +160,9 @@ inline RawVolume read_mhd(const std::string &path) {
     else if (key == "DimSize") is >> v.size[0] >> v.size[1] >> v.size[2];
     else if (key == "ElementSpacing" || key == "ElementSize") is >> v.spacing[0] >> v.spacing[1] >> v.spacing[2];
     else if (key == "Offset" || key == "Position") is >> v.origin[0] >> v.origin[1] >> v.origin[2];
+    else if (key == "TransformMatrix" || key == "Rotation" || key == "Orientation") { v.geom.has_mhd = true; v.geom.mhd_transform = val; }
+    else if (key == "CenterOfRotation") { v.geom.has_mhd = true; v.geom.mhd_center = val; }
+    else if (key == "AnatomicalOrientation") { v.geom.has_mhd = true; v.geom.mhd_orientation = val; }
     else if (key == "ElementType") etype = val;
     else if (key == "ElementDataFile") datafile = val;
     else if (key == "ElementByteOrderMSB" || key == "BinaryDataByteOrderMSB") {
@@ -155,6 +173,13 @@ inline RawVolume read_mhd(const std::string &path) {
     }
   }
   if (ndims != 3) throw ExceptionObject(path + " is not 3-D", "ImageFileReader");
+  for (int a = 0; a < 3; ++a) {
+    if (v.size[a] < 1 || v.size[a] > ((uint64_t)1 << 31))
+      throw ExceptionObject(path + ": missing or absurd DimSize", "ImageFileReader");
+    if (!(v.spacing[a] > 0.0) || !std::isfinite(v.spacing[a])) v.spacing[a] = 1.0;
+  }
+  if (v.size[0] * v.size[1] > ((uint64_t)1 << 62) / v.size[2] / 8)
+    throw ExceptionObject(path + ": volume too large", "ImageFileReader");
   if (etype == "MET_FLOAT") v.nifti_type = 16;
   else if (etype == "MET_DOUBLE") v.nifti_type = 64;
   else if (etype == "MET_UCHAR") v.nifti_type = 2;
@@ -214,6 +239,9 @@ inline void write_nifti(const std::string &path, const ImageBase3 &info, const T
   const Size3 &sz = info.GetLargestPossibleRegion().GetSize();
   h.dim[0] = 3;
   for (int a = 0; a < 3; ++a) {
+    if (sz[a] > 32767)
+      throw ExceptionObject("an axis longer than 32767 voxels does not fit NIfTI-1 (use .mhd): " + path,
+                            "ImageFileWriter");
     h.dim[1 + a] = (int16_t)sz[a];
     h.pixdim[1 + a] = (float)info.GetSpacing()[a];
   }
@@ -233,6 +261,17 @@ inline void write_nifti(const std::string &path, const ImageBase3 &info, const T
   h.srow_x[0] = h.pixdim[1]; h.srow_x[3] = h.qoffset_x;
   h.srow_y[1] = h.pixdim[2]; h.srow_y[3] = h.qoffset_y;
   h.srow_z[2] = h.pixdim[3]; h.srow_z[3] = h.qoffset_z;
+  const FileGeometry &fg = info.GetFileGeometry();
+  if (fg.has_nifti) {  // the world geometry of the source file, as it was
+    h.qform_code = fg.qform_code; h.sform_code = fg.sform_code;
+    h.pixdim[0] = fg.qfac;
+    h.quatern_b = fg.quatern[0]; h.quatern_c = fg.quatern[1]; h.quatern_d = fg.quatern[2];
+    h.qoffset_x = fg.qoffset[0]; h.qoffset_y = fg.qoffset[1]; h.qoffset_z = fg.qoffset[2];
+    std::memcpy(h.srow_x, fg.srow[0], sizeof h.srow_x);
+    std::memcpy(h.srow_y, fg.srow[1], sizeof h.srow_y);
+    std::memcpy(h.srow_z, fg.srow[2], sizeof h.srow_z);
+    h.xyzt_units = fg.xyzt_units;
+  }
   std::memcpy(h.magic, "n+1", 4);
   const unsigned char ext[4] = {0, 0, 0, 0};
   const size_t nb = (size_t)(sz[0] * sz[1] * sz[2]) * sizeof(T);
@@ -272,8 +311,14 @@ inline void write_mhd(const std::string &path, const ImageBase3 &info, const T *
   if (!h) throw ExceptionObject("cannot create " + path, "ImageFileWriter");
   h.precision(17);
   h << "ObjectType = Image\nNDims = 3\nBinaryData = True\nBinaryDataByteOrderMSB = False\n"
-    << "CompressedData = False\n"
-    << "Offset = " << info.GetOrigin()[0] << " " << info.GetOrigin()[1] << " " << info.GetOrigin()[2] << "\n"
+    << "CompressedData = False\n";
+  const FileGeometry &fg = info.GetFileGeometry();
+  if (fg.has_mhd) {
+    if (!fg.mhd_transform.empty()) h << "TransformMatrix = " << fg.mhd_transform << "\n";
+    if (!fg.mhd_center.empty()) h << "CenterOfRotation = " << fg.mhd_center << "\n";
+    if (!fg.mhd_orientation.empty()) h << "AnatomicalOrientation = " << fg.mhd_orientation << "\n";
+  }
+  h << "Offset = " << info.GetOrigin()[0] << " " << info.GetOrigin()[1] << " " << info.GetOrigin()[2] << "\n"
     << "ElementSpacing = " << info.GetSpacing()[0] << " " << info.GetSpacing()[1] << " " << info.GetSpacing()[2] << "\n"
     << "DimSize = " << sz[0] << " " << sz[1] << " " << sz[2] << "\n"
     << "ElementType = " << et << "\n"
@@ -305,6 +350,7 @@ class ImageFileReader {
     img->SetRegions(v.size);
     img->SetSpacing(v.spacing);
     img->SetOrigin(v.origin);
+    img->SetFileGeometry(v.geom);
     img->Allocate();
     convert_any<typename TImage::PixelType>(v, img->GetBufferPointer());
     out_ = img;

@@ -72,6 +72,7 @@ int main(int argc, char *argv[]) {
     featureFilter->SetInputImage(reader->GetOutput());
     featureFilter->SetInputMask(clampFilter->GetOutput());
     indexSelectionFilter->SetInput(featureFilter->GetOutput());
+    featureFilter->SetScales(scales);  // all scales start on the device at the first Update()
     for (auto scale : scales) {
       featureFilter->SetSigma(scale);
       for (unsigned int i = 0; i < featureNames.size(); ++i) {

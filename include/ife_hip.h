@@ -173,6 +173,20 @@ int ife_emphysema_features(ife_ctx *ctx, const void *image, int image_dtype, con
                            int mask_dtype, const ife_volume_desc *vol, const float *sigmas,
                            int n_sigmas, float *out, int layout, int mem);
 
+/* The scale loop of tools/ExtractFeatures.cxx:132-154 as a stream: _begin uploads image and
+ * mask ONCE (host pointers), runs Cast + Multiply once and enqueues every scale, leaving the
+ * outputs in device memory owned by the context; _fetch(scale) blocks until that scale has
+ * finished and copies its 8-component volume (`layout` of _begin) to host memory on a copy
+ * stream of its own -- so a caller can write scale k to disk while the device is still busy
+ * with the later scales, and never holds more than one scale in host memory; _end frees the
+ * device copy (also done by the next _begin and by ife_ctx_destroy).  IFE_E_STATE when a
+ * scale is fetched that _begin did not start. */
+int ife_emphysema_features_begin(ife_ctx *ctx, const void *image, int image_dtype,
+                                 const void *mask, int mask_dtype, const ife_volume_desc *vol,
+                                 const float *sigmas, int n_sigmas, int layout);
+int ife_emphysema_features_fetch(ife_ctx *ctx, int scale, float *out);
+int ife_emphysema_features_end(ife_ctx *ctx);
+
 /* ---- a6 / a7 / a8: tool bodies ---------------------------------------------------- */
 
 /* Body of tools/FiniteDifference_HessianFeatures.cxx:126-229 (un-smoothed Hessian,

@@ -9,7 +9,20 @@ _CODES = {np.dtype(np.uint8): 2, np.dtype(np.int16): 4, np.dtype(np.uint16): 512
 _DTYPES = {v: k for k, v in _CODES.items()}
 
 
-def write(path, vol_zyx, spacing_xyz=(1.0, 1.0, 1.0)):
+GEOM_FIELDS = (("qform_code", "<h", 252), ("sform_code", "<h", 254), ("quatern", "<3f", 256),
+               ("qoffset", "<3f", 268), ("srow_x", "<4f", 280), ("srow_y", "<4f", 296),
+               ("srow_z", "<4f", 312), ("qfac", "<f", 76))
+
+
+def read_geometry(path):
+    """The world-geometry fields of the header, as raw tuples."""
+    raw = gzip.open(path, "rb").read(352) if path.endswith(".gz") else open(path, "rb").read(352)
+    return {k: struct.unpack_from(f, raw, o) for k, f, o in GEOM_FIELDS}
+
+
+def write(path, vol_zyx, spacing_xyz=(1.0, 1.0, 1.0), geometry=None, patch=None):
+    """geometry: {field: tuple} of GEOM_FIELDS to set; patch: [(fmt, offset, values...)] raw
+    header edits (malformed-header tests)."""
     vol = np.ascontiguousarray(vol_zyx)
     nz, ny, nx = vol.shape
     h = bytearray(348)
@@ -20,6 +33,11 @@ def write(path, vol_zyx, spacing_xyz=(1.0, 1.0, 1.0)):
     struct.pack_into("<f", h, 108, 352.0)
     struct.pack_into("<f", h, 112, 1.0)
     h[344:348] = b"n+1\0"
+    for k, f, o in GEOM_FIELDS:
+        if geometry and k in geometry:
+            struct.pack_into(f, h, o, *geometry[k])
+    for f, o, *vals in (patch or []):
+        struct.pack_into(f, h, o, *vals)
     data = bytes(h) + b"\0\0\0\0" + vol.tobytes()
     if path.endswith(".gz"):
         with gzip.open(path, "wb", compresslevel=1) as f:

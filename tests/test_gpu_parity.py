@@ -219,6 +219,21 @@ def test_emphysema_int16_image_u16_mask_labels(ctx, oracle, synth):
     assert_features_close(got, ref, labels)
 
 
+def test_emphysema_stream_equals_one_call(ctx, ife, synth):
+    """begin / fetch / end (upload and prepass once, scale by scale to the host) returns the
+    volumes of the one-call form; fetching a scale that was not started is a state error."""
+    shape = (24, 28, 32)
+    img = synth.volume_i16(shape, 13)
+    mask = np.minimum(synth.mask_ellipsoids(shape), 1).astype(np.uint16)
+    sig = [1.0, 2.0, 3.0, 4.0]  # more scales than run through the line kernels at once
+    whole = ctx.emphysema_features(img, mask, sig, (0.7, 0.7, 1.0))
+    for k, vol in enumerate(ctx.emphysema_features_stream(img, mask, sig, (0.7, 0.7, 1.0))):
+        np.testing.assert_array_equal(vol, whole[k])
+    out = np.empty(shape + (8,), np.float32)
+    rc = ctx._lib.ife_emphysema_features_fetch(ctx._h, 0, out.ctypes.data)
+    assert rc == ife.E_STATE
+
+
 def test_emphysema_null_mask_equals_ones_mask(ctx, synth):
     shape = (24, 28, 32)
     img = synth.volume_f32(shape, 11)

@@ -80,6 +80,86 @@ def test_missing_input_file(built, tmp_path):
     assert r.returncode == 1 and "cannot open" in r.stderr
 
 
+@pytest.mark.parametrize("what,patch,msg", [
+    ("negative dim", [("<h", 42, -5)], "non-positive dimension"),
+    ("zero dim", [("<h", 46, 0)], "non-positive dimension"),
+    ("nan vox_offset", [("<f", 108, float("nan"))], "bad vox_offset"),
+    ("huge vox_offset", [("<f", 108, 3.0e38)], "bad vox_offset"),
+    ("vox_offset inside the header", [("<f", 108, 100.0)], "bad vox_offset"),
+    ("more voxels than bytes", [("<h", 44, 3000)], "truncated voxel data"),
+])
+def test_malformed_nifti_headers_are_refused(built, tmp_path, what, patch, msg):
+    """Header fields of an untrusted file are checked before they size anything."""
+    niftiio.write(str(tmp_path / "bad.nii"), np.zeros((4, 5, 6), np.float32), patch=patch)
+    niftiio.write(str(tmp_path / "ok.nii"), np.zeros((4, 5, 6), np.float32))
+    r = run("MaskedImageFilter", "-i", str(tmp_path / "bad.nii"), "-m", str(tmp_path / "ok.nii"),
+            "-o", str(tmp_path / "o.nii"))
+    assert r.returncode == 1 and msg in r.stderr, (what, r.stderr)
+
+
+def test_malformed_metaimage_is_refused(built, tmp_path):
+    (tmp_path / "v.raw").write_bytes(b"\0" * 16)
+    for dims in ("0 4 4", "4 4", "99999999999 4 4"):
+        (tmp_path / "v.mhd").write_text("NDims = 3\nDimSize = %s\nElementType = MET_FLOAT\n"
+                                        "ElementDataFile = v.raw\n" % dims)
+        r = run("MaskedImageFilter", "-i", str(tmp_path / "v.mhd"), "-m", str(tmp_path / "v.mhd"),
+                "-o", str(tmp_path / "o.nii"))
+        assert r.returncode == 1 and ("DimSize" in r.stderr or "too large" in r.stderr
+                                      or "truncated" in r.stderr), r.stderr
+
+
+def test_host_tools_under_sanitizers(tmp_path, synth):
+    """AddressSanitizer + UBSan build of the host side (`make SANITIZE=1 BINDIR=bin_san`),
+    run over the paths that need no GPU: usage, argument errors, file reading, malformed
+    headers, ROI generation, and the loud failure where the device would be needed."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "image-feature-extraction_amd", "csrc")])
+    subprocess.check_call(["make", "-s", "-j", "8", "-C", HOST, "SANITIZE=1", "BINDIR=bin_san"])
+    san = os.path.join(HOST, "bin_san")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    niftiio.write(str(tmp_path / "i.nii.gz"), synth.volume_f32((8, 9, 10), 1))
+    niftiio.write(str(tmp_path / "m.nii.gz"), np.ones((8, 9, 10), np.uint16))
+    niftiio.write(str(tmp_path / "bad.nii"), np.zeros((4, 5, 6), np.float32), patch=[("<f", 108, float("nan"))])
+    (tmp_path / "rois.txt").write_text("index size\n[1, 1, 1][3, 3, 3]\n")
+    (tmp_path / "h.txt").write_text("# c\n0,1,2\n")
+    i, m = str(tmp_path / "i.nii.gz"), str(tmp_path / "m.nii.gz")
+    cases = [["ExtractFeatures", "--help"], ["MakeBagDense", "--help"], ["MakeBag", "-i", "x"],
+             ["ExtractFeatures", "-i", i, "-m", m, "-o", str(tmp_path / "o"), "-s", "1", "-s", "2"],
+             ["MaskedImageFilter", "-i", str(tmp_path / "bad.nii"), "-m", m, "-o", str(tmp_path / "o.nii")],
+             ["MakeBagOnlyIntensity", "-i", i, "-m", m, "-H", str(tmp_path / "h.txt"), "-o", str(tmp_path),
+              "-r", str(tmp_path / "rois.txt")],
+             ["MakeBagDense", "-i", i, "-m", m, "-H", str(tmp_path / "h.txt"), "-o", str(tmp_path), "-s", "1",
+              "-x", "3", "-y", "3", "-z", "3"],
+             ["DetermineHistogramBinEdges_MultiScaleEigenvalueFeatures", "-i", str(tmp_path / "nolist.txt"),
+              "-o", str(tmp_path / "e.txt"), "-b", "4", "-S", "0", "-s", "1", "-f", "1"]]
+    for c in cases:
+        r = subprocess.run([os.path.join(san, c[0])] + c[1:], capture_output=True, text=True, env=env)
+        assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (c, r.stderr[-1500:])
+        assert r.returncode in (0, 1), (c, r.returncode, r.stderr[-500:])
+
+
+@pytest.mark.gpu
+def test_world_geometry_survives_the_tools(built, tmp_path, synth):
+    """A volume written by ITK carries an LPS qform/sform (quatern_d = 1, negated x/y
+    offsets).  The tools compute with the spacing only, but their outputs must overlay the
+    source: every geometry field of the header comes back as it went in."""
+    shape = (8, 9, 10)
+    geom = {"qform_code": (1,), "sform_code": (1,), "quatern": (0.0, 0.0, 1.0), "qoffset": (12.5, -7.25, 33.0),
+            "srow_x": (-0.7, 0.0, 0.0, 12.5), "srow_y": (0.0, -0.8, 0.0, -7.25), "srow_z": (0.0, 0.0, 1.25, 33.0),
+            "qfac": (1.0,)}
+    niftiio.write(str(tmp_path / "i.nii.gz"), synth.volume_f32(shape, 3), (0.7, 0.8, 1.25), geometry=geom)
+    niftiio.write(str(tmp_path / "m.nii.gz"), np.ones(shape, np.uint8), (0.7, 0.8, 1.25), geometry=geom)
+    want = niftiio.read_geometry(str(tmp_path / "i.nii.gz"))
+    r = run("ExtractFeatures", "-i", str(tmp_path / "i.nii.gz"), "-m", str(tmp_path / "m.nii.gz"),
+            "-o", str(tmp_path / "o"), "-s", "1")
+    assert r.returncode == 0, r.stderr
+    got = niftiio.read_geometry(str(tmp_path / ("o_scale_1.000000GaussianBlur.nii.gz")))
+    assert got == want
+    r = run("MaskedImageFilter", "-i", str(tmp_path / "i.nii.gz"), "-m", str(tmp_path / "m.nii.gz"),
+            "-o", str(tmp_path / "masked.nii"))
+    assert r.returncode == 0, r.stderr
+    assert niftiio.read_geometry(str(tmp_path / "masked.nii")) == want
+
+
 @pytest.mark.gpu
 def test_host_selftest(built, tmp_path):
     r = subprocess.run([os.path.join(BIN, "host_selftest"), str(tmp_path)], capture_output=True, text=True)
@@ -207,6 +287,74 @@ def test_histogram_edges_tool(built, tmp_path, synth, oracle):
     # more bins than samples: the reference throws std::out_of_range; here a message and EXIT_FAILURE
     bad = run(tool, *[x if x != str(nbins) else "100000" for x in args], "-S", "10")
     assert bad.returncode == 1 and "Too many bins" in bad.stderr
+
+
+def test_bag_variant_flags(built):
+    """The variants register exactly the flags the reference's variants read
+    (tools/MakeBagDense.cxx has no -r/-R/-n, tools/MakeBagOnlyIntensity.cxx no -s)."""
+    d = run("MakeBagDense", "--help").stdout
+    assert "--scale" in d and "--roi-mask" in d and "--roi-file" not in d and "--num-rois" not in d
+    i = run("MakeBagOnlyIntensity", "--help").stdout
+    assert "--roi-file" in i and "--num-rois" in i and "--scale" not in i
+    assert run("MakeBagDense", "-i", "a", "-m", "b", "-H", "c", "-o", "d", "-s", "1", "-n", "3").returncode == 1
+    assert run("MakeBagOnlyIntensity", "-i", "a", "-m", "b", "-H", "c", "-o", "d", "-s", "1").returncode == 1
+
+
+@pytest.mark.gpu
+def test_makebag_dense_and_only_intensity(built, tmp_path, synth, oracle):
+    """MakeBagDense: one region per mask voxel whose box fits, in raster order
+    (DenseROIGenerator.hxx:24-46), rows against the oracle.  MakeBagOnlyIntensity: the image
+    itself binned by one histogram (MakeBagOnlyIntensity.cxx:355-389)."""
+    shape, scales, nbins = (10, 12, 14), [1.0], 5
+    img = synth.volume_f32(shape, 402)
+    lab = np.zeros(shape, np.uint16)
+    lab[3:7, 2:9, 4:11] = 2
+    lab[0, 0, 0] = 1                                  # a mask voxel whose box does not fit
+    niftiio.write(str(tmp_path / "img.nii.gz"), img)
+    niftiio.write(str(tmp_path / "lab.nii.gz"), lab)
+    clamped = np.minimum(lab, 1).astype(np.uint8)
+    feat = oracle.emphysema_features(img, clamped, 1.0)
+    edges = np.stack([oracle.equalized_edges(oracle.sort_f32(feat[..., c][clamped != 0]), nbins)
+                      for c in range(8)])
+    edges32 = np.array([[np.float32(float("%.9g" % v)) for v in row] for row in edges], np.float32)
+    (tmp_path / "hist.txt").write_text("".join(",".join("%.9g" % v for v in row) + "\n" for row in edges))
+    os.mkdir(str(tmp_path / "out"))
+    sx, sy, sz = 5, 3, 3
+    r = run("MakeBagDense", "-i", str(tmp_path / "img.nii.gz"), "-m", str(tmp_path / "lab.nii.gz"),
+            "-H", str(tmp_path / "hist.txt"), "-o", str(tmp_path / "out"), "-s", "1",
+            "-x", str(sx), "-y", str(sy), "-z", str(sz), "-p", "dense")
+    assert r.returncode == 0, r.stderr
+    want_boxes = []
+    for z, y, x in zip(*np.nonzero(lab)):             # np.nonzero walks z, y, x: raster order
+        x0, y0, z0 = x - sx // 2, y - sy // 2, z - sz // 2
+        if x0 >= 0 and y0 >= 0 and z0 >= 0 and x0 + sx <= 14 and y0 + sy <= 12 and z0 + sz <= 10:
+            want_boxes.append((x0, y0, z0, sx, sy, sz))
+    info = (tmp_path / "out" / "dense.ROIInfo").read_text().splitlines()
+    assert info == ["[%d, %d, %d][%d, %d, %d]" % b for b in want_boxes] and len(info) == 4 * 7 * 7
+    rows = (tmp_path / "out" / "dense.bag").read_text().splitlines()
+    assert len(rows) == len(want_boxes)
+    boxes = np.array(want_boxes, np.int64)
+    for j in range(0, len(rows), 17):
+        _, fr = oracle.roi_histograms(feat, clamped, boxes[j:j + 1], edges32)
+        assert [t.replace("-nan", "nan") for t in rows[j].split(",")] == ["%g" % v for v in fr.ravel()], j
+    # intensity only: one histogram, regions from a file
+    iedges = np.array([-500.0, 0.0, 500.0, 1500.0], np.float32)
+    (tmp_path / "ihist.txt").write_text("# intensity\n" + ",".join("%.9g" % v for v in iedges) + "\n")
+    (tmp_path / "rois.txt").write_text("index size\n[1, 1, 1][6, 5, 4]\n[7, 6, 5][7, 6, 5]\n[0, 0, 7][3, 3, 3]\n")
+    r = run("MakeBagOnlyIntensity", "-i", str(tmp_path / "img.nii.gz"), "-m", str(tmp_path / "lab.nii.gz"),
+            "-H", str(tmp_path / "ihist.txt"), "-o", str(tmp_path / "out"), "-r", str(tmp_path / "rois.txt"),
+            "-p", "int")
+    assert r.returncode == 0, r.stderr
+    rows = (tmp_path / "out" / "int.bag").read_text().splitlines()
+    assert len(rows) == 3
+    for row, (x0, y0, z0, bx, by, bz) in zip(rows, ((1, 1, 1, 6, 5, 4), (7, 6, 5, 7, 6, 5), (0, 0, 7, 3, 3, 3))):
+        v = img[z0:z0 + bz, y0:y0 + by, x0:x0 + bx][lab[z0:z0 + bz, y0:y0 + by, x0:x0 + bx] != 0]
+        cnt = np.bincount(np.searchsorted(iedges, v, side="left"), minlength=5)  # (-inf,e0], (e0,e1], ...
+        fr = cnt.astype(np.float32) / np.float32(cnt.sum()) if cnt.sum() else np.full(5, np.nan, np.float32)
+        assert [t.replace("-nan", "nan") for t in row.split(",")] == ["%g" % f for f in fr]
+    two = run("MakeBagOnlyIntensity", "-i", str(tmp_path / "img.nii.gz"), "-m", str(tmp_path / "lab.nii.gz"),
+              "-H", str(tmp_path / "hist.txt"), "-o", str(tmp_path / "out"), "-r", str(tmp_path / "rois.txt"))
+    assert two.returncode == 1 and "Expected exactly one histogram" in two.stderr
 
 
 def test_makebag_usage(built):
