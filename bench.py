@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--force-slab", action="store_true",
                     help="run the Z-slab engine (RCCL exchanges) even with one rank")
     ap.add_argument("--cpu-sample", type=int, default=512, help="edge of the CPU baseline cube")
+    ap.add_argument("--scales-per-item", type=int, default=None,
+                    help="N>1: scales whose boundary sweeps share a launch and a message (slab.py)")
     ap.add_argument("--line-groups", type=int, default=None,
                     help="N>1: items per scale on the boundary-state chains (slab.py)")
     return ap.parse_args()

@@ -21,10 +21,10 @@ Everything is slab-local except two things:
 Per step and rank (S scales, nf = 2 fields with a mask, G line groups per scale):
 
   prepare                       tc = image*mask, cf = float(mask)                (local)
-  chain stream, items (s, g) in expected-arrival order:
-      C(s, g): [recv state from r-1] causal sweep     [send state to r+1]
-      A(s, g): [recv state from r+1] anticausal sweep [send state to r-1]
-  bulk stream, per scale group:
+  chain stream, items (scale group q, line group g) in expected-arrival order:
+      C(q, g): [recv state from r-1] causal sweep     [send state to r+1]
+      A(q, g): [recv state from r+1] anticausal sweep [send state to r-1]
+  bulk stream, per scale group (all scales up to four ranks, else one scale):
       combine (Z output), X pass, Y pass, halo exchange, features               (local)
 
 Bytes over xGMI per boundary, direction and step: 48 B x nx*ny x S x nf (512^2, 3 scales,
@@ -222,10 +222,17 @@ class SlabEngine:
     """Runs all scales of the feature path on this rank's Z-slab."""
 
     def __init__(self, stages, comm, shape_zyx, spacing, sigmas, rank, world, alloc, layout,
-                 has_mask=True, overlap=True, line_groups=None, bounds=None, streams=None):
+                 has_mask=True, overlap=True, line_groups=None, bounds=None, streams=None,
+                 scales_per_item=None):
         """alloc(shape, dtype_name) -> tensor ('float32' or 'uint8') on the compute device;
-        bounds: W+1 plane indices (default: slab_bounds); line_groups: items per scale on the
-        boundary chains (default 2 when world > 2, else 1); streams: a _Streams (GPU)."""
+        bounds: W+1 plane indices (default: slab_bounds); line_groups: items per scale group on
+        the boundary chains (default 2 when world > 2, else 1); scales_per_item: scales whose
+        sweeps share a launch and a message (default: all of them up to four ranks -- the jobs of
+        a launch share their input through L2 and the 64-plane launches of one scale leave most of
+        the device idle: 512^3 on a 128-plane slab 3.13 ms per step against 3.61 -- else one, so
+        that with eight ranks, where the 75 MB per boundary take longer than the local work, the
+        first scale leaves the chains early and computes while the others travel);
+        streams: a _Streams (GPU)."""
         nz, ny, nx = shape_zyx
         self.bounds = list(bounds) if bounds is not None else slab_bounds(nz, world)
         if len(self.bounds) != world + 1 or self.bounds[0] != 0 or self.bounds[-1] != nz:
@@ -248,7 +255,12 @@ class SlabEngine:
         G = max(1, min(G, (L + 255) // 256))
         per = ((L + G - 1) // G + 255) // 256 * 256  # whole workgroups of 256 lines
         self.groups = [(l0, min(L, l0 + per) - l0) for l0 in range(0, L, per)]
-        self.items = [(s, g) for s in range(S) for g in range(len(self.groups))]
+        max_jobs = max(1, 8 // nf)                     # jobs of one launch (IIR_MAX_JOBS = 8)
+        spi = scales_per_item if scales_per_item else (S if world <= 4 else 1)
+        spi = max(1, min(spi, max_jobs, S))
+        # scale groups: their sweeps share launches and messages; the bulk phase follows them
+        self.scale_groups = [list(range(s0, min(S, s0 + spi))) for s0 in range(0, S, spi)]
+        self.items = [(q, g) for q in range(len(self.scale_groups)) for g in range(len(self.groups))]
         self.schedule = sweep_schedule(rank, world, len(self.items))
         f = lambda *shp: alloc(shp, "float32")
         self.src = [f(nzl, ny, nx) for _ in range(nf)]                      # tc, cf
@@ -257,19 +269,15 @@ class SlabEngine:
         self.pad = [[f(nzl + 2, ny, nx) for _ in range(nf)] for _ in range(S)]  # Y output + halo planes
         ckb = stages.ck_bytes((nzl, ny, nx))
         self.ck = [[alloc((ckb,), "uint8") for _ in range(nf)] for _ in range(S)]
-        sb = lambda nl: alloc((nf * STATE_BYTES_PER_LINE * nl,), "uint8")
-        self.c_in = [sb(self.groups[g][1]) for _, g in self.items]
-        self.c_out = [sb(self.groups[g][1]) for _, g in self.items]
-        self.a_in = [sb(self.groups[g][1]) for _, g in self.items]
-        self.a_out = [sb(self.groups[g][1]) for _, g in self.items]
+        sb = lambda q, g: alloc((len(self.scale_groups[q]) * nf * STATE_BYTES_PER_LINE
+                                 * self.groups[g][1],), "uint8")
+        self.c_in = [sb(q, g) for q, g in self.items]
+        self.c_out = [sb(q, g) for q, g in self.items]
+        self.a_in = [sb(q, g) for q, g in self.items]
+        self.a_out = [sb(q, g) for q, g in self.items]
         n = len(self.items)
         self.sent = [[None] * n, [None] * n]      # pending sends of the previous step
         self.consumed = [[None] * n, [None] * n]  # events: in-state read by its sweep
-        # scales of the bulk phase: the first alone (it can start while the states of the later
-        # ones are still travelling), the rest in launches of up to 8 jobs
-        per_launch = max(1, 8 // nf)
-        self.scale_groups = [[0]] + [list(range(s0, min(S, s0 + per_launch)))
-                                     for s0 in range(1, S, per_launch)]
 
     # ---- one step -------------------------------------------------------------------
     def run(self, img_slab, mask_slab, out):
@@ -308,7 +316,8 @@ class SlabEngine:
         with on(chain):
             wait(chain, prepared)
             for d, i in self.schedule:
-                s, g = self.items[i]
+                q, g = self.items[i]
+                ss = self.scale_groups[q]
                 l0, nl = self.groups[g]
                 has_nb = has_lo if d == 0 else has_hi
                 sin = (self.c_in if d == 0 else self.a_in)[i]
@@ -318,8 +327,9 @@ class SlabEngine:
                 if self.sent[d][i] is not None:  # last step's send still reads sout
                     self.sent[d][i].wait()
                     self.sent[d][i] = None
-                st.z_sweep(d, self.src[:nf], sp, [self.sigmas[s]] * nf, l0, nl, has_nb, sin, sout,
-                           self.ck[s][:nf])
+                st.z_sweep(d, [self.src[k] for _ in ss for k in range(nf)], sp,
+                           [self.sigmas[s] for s in ss for _ in range(nf)], l0, nl, has_nb, sin, sout,
+                           [self.ck[s][k] for s in ss for k in range(nf)])
                 swept[d][i] = rec(chain)
                 self.consumed[d][i] = swept[d][i]
                 if d == 0 and has_hi:
@@ -328,9 +338,9 @@ class SlabEngine:
                     self.sent[d][i] = comm.isend_down(sout)
 
         first = 0 if has_lo else 1
-        for ss in self.scale_groups:
-            for i, (s, g) in enumerate(self.items):
-                if s in ss:
+        for q, ss in enumerate(self.scale_groups):
+            for i, (qi, g) in enumerate(self.items):
+                if qi == q:
                     wait(bulk, swept[0][i])
                     wait(bulk, swept[1][i])
             sg = [self.sigmas[s] for s in ss for _ in range(nf)]
@@ -403,10 +413,12 @@ class SlabRunner:
                                  TorchComm(dist, rank, world), shape, spacing, sigmas, rank, world,
                                  alloc, layout, has_mask=self.d_mask is not None,
                                  streams=self.streams,
-                                 line_groups=getattr(args, "line_groups", None))
+                                 line_groups=getattr(args, "line_groups", None),
+                                 scales_per_item=getattr(args, "scales_per_item", None))
         # what was actually built, for the bench line
         self.config = {"input": "int16" if i16 else "float32", "spacing": list(spacing),
-                       "slab_planes": nzl, "line_groups": len(self.engine.groups)}
+                       "slab_planes": nzl, "line_groups": len(self.engine.groups),
+                       "scales_per_item": len(self.engine.scale_groups[0])}
 
     def step(self):
         self.engine.run(self.d_img, self.d_mask, self.d_out)

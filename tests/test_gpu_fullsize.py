@@ -126,7 +126,7 @@ def test_chunking_and_block_size_are_invisible_at_full_size(ife, dev):
         run(ife, dev, dev["img"], dev["mask"], 4.0, dev["out_b"])
     finally:
         ctx.set_option(ife.OPT_ZCHUNK, 64)
-        ctx.set_option(ife.OPT_IIR_BLOCK, 12)  # the default
+        ctx.set_option(ife.OPT_IIR_BLOCK, 0)  # the default
     assert bool(torch.equal(dev["out_a"], dev["out_b"]))
 
 

@@ -154,7 +154,7 @@ class OracleStages:
         out.copy_(torch.from_numpy(res))
 
 
-def _worker(rank, world, port, shape, sigmas, spacing, use_hip, bounds, line_groups, steps, ret):
+def _worker(rank, world, port, shape, sigmas, spacing, use_hip, bounds, line_groups, steps, spi, ret):
     sys.path.insert(0, ROOT)
     os.environ["IFE_TRIG_MODE"] = "0"
     import torch
@@ -193,7 +193,7 @@ def _worker(rank, world, port, shape, sigmas, spacing, use_hip, bounds, line_gro
         alloc = lambda shp, d: torch.empty(shp, dtype=dt[d], device=dev)
         eng = slab.SlabEngine(stages, comm, shape, spacing, sigmas, rank, world, alloc,
                               pkg.INTERLEAVED, has_mask=True, bounds=bounds,
-                              line_groups=line_groups, streams=streams)
+                              line_groups=line_groups, streams=streams, scales_per_item=spi)
         out = torch.empty((len(sigmas), nzl, ny, nx, 8), dtype=torch.float32, device=dev)
         d_img, d_mask = torch.from_numpy(img).to(dev), torch.from_numpy(mask).to(dev)
         for _ in range(steps):  # a second step reuses every buffer and pending send
@@ -208,11 +208,11 @@ def _worker(rank, world, port, shape, sigmas, spacing, use_hip, bounds, line_gro
 
 
 def _run_world(world, shape, sigmas, spacing, use_hip, tmp_path, bounds=None, line_groups=None,
-               steps=1):
+               steps=1, spi=None):
     import torch.multiprocessing as mp
     port = _free_port()
     mp.spawn(_worker, args=(world, port, shape, sigmas, spacing, use_hip, bounds, line_groups,
-                            steps, str(tmp_path)), nprocs=world, join=True)
+                            steps, spi, str(tmp_path)), nprocs=world, join=True)
     parts = [np.load(os.path.join(str(tmp_path), "out_%d.npy" % r)) for r in range(world)]
     return np.concatenate(parts, axis=1)  # along z
 
@@ -224,15 +224,15 @@ def _whole_volume(synth, shape):
     return img, mask
 
 
-@pytest.mark.parametrize("world,shape,spacing,bounds,groups,steps", [
-    (2, (16, 20, 12), (1.0, 1.0, 1.0), None, 1, 2),
-    (3, (19, 40, 30), (1.0, 1.0, 1.0), [0, 4, 11, 19], 3, 1),     # uneven cut, 3 line groups
-    (4, (29, 24, 40), (0.8, 1.0, 1.25), None, 2, 2),               # 8,7,7,7 planes
+@pytest.mark.parametrize("world,shape,spacing,bounds,groups,steps,spi", [
+    (2, (16, 20, 12), (1.0, 1.0, 1.0), None, 1, 2, None),          # all scales in one item
+    (3, (19, 40, 30), (1.0, 1.0, 1.0), [0, 4, 11, 19], 3, 1, 2),   # uneven cut, 3 line groups, scales 2 + 1
+    (4, (29, 24, 40), (0.8, 1.0, 1.25), None, 2, 2, None),         # 8,7,7,7 planes, one scale per item
 ])
 def test_slab_engine_equals_single_process_oracle(oracle, synth, tmp_path, world, shape, spacing,
-                                                  bounds, groups, steps):
+                                                  bounds, groups, steps, spi):
     sigmas = [1.0, 2.0, 3.5]
-    got = _run_world(world, shape, sigmas, spacing, False, tmp_path, bounds, groups, steps)
+    got = _run_world(world, shape, sigmas, spacing, False, tmp_path, bounds, groups, steps, spi)
     img, mask = _whole_volume(synth, shape)
     for s, sigma in enumerate(sigmas):
         ref = oracle.emphysema_features(img, mask, sigma, spacing)
