@@ -35,7 +35,8 @@ EXPORTS = (
     "ife_abi_version", "ife_ctx_create", "ife_ctx_destroy", "ife_last_error",
     "ife_ctx_set_stream", "ife_ctx_set_option", "ife_ctx_reserve", "ife_ctx_synchronize",
     "ife_eigenvalues", "ife_eigenvalue_features", "ife_hessian3d", "ife_gradient_magnitude",
-    "ife_normalized_gaussian_convolution", "ife_emphysema_features",
+    "ife_normalized_gaussian_convolution", "ife_differential_normalized_convolution",
+    "ife_emphysema_features",
     "ife_emphysema_features_begin", "ife_emphysema_features_fetch", "ife_emphysema_features_end",
     "ife_fd_hessian_features", "ife_fd_gradient_features", "ife_mask_image_f64",
     "ife_get_kernel_times", "ife_reset_kernel_times",
@@ -101,6 +102,7 @@ def load_library():
     lib.ife_hessian3d.argtypes = [vp, f32p, vd, f32p, i32, i32]
     lib.ife_gradient_magnitude.argtypes = [vp, f32p, vd, f32p, i32]
     lib.ife_normalized_gaussian_convolution.argtypes = [vp, f32p, f32p, vd, C.c_double, f32p, i32]
+    lib.ife_differential_normalized_convolution.argtypes = [vp, f32p, f32p, vd, C.c_double, i32, f32p, i32]
     lib.ife_emphysema_features.argtypes = [vp, vp, i32, vp, i32, vd, C.POINTER(C.c_float), i32,
                                            f32p, i32, i32]
     lib.ife_emphysema_features_begin.argtypes = [vp, vp, i32, vp, i32, vd, C.POINTER(C.c_float), i32, i32]
@@ -252,6 +254,17 @@ class Context:
         self._chk(self._lib.ife_normalized_gaussian_convolution(
             self._h, image.ctypes.data, certainty.ctypes.data, C.byref(d), float(sigma),
             out.ctypes.data, MEM_HOST))
+        return out
+
+    def differential_normalized_convolution(self, image, certainty, sigma, axis_xyz,
+                                            spacing=(1.0, 1.0, 1.0)):
+        image = np.ascontiguousarray(image, np.float32)
+        certainty = np.ascontiguousarray(certainty, np.float32)
+        d = _desc(image.shape, spacing)
+        out = np.empty_like(image)
+        self._chk(self._lib.ife_differential_normalized_convolution(
+            self._h, image.ctypes.data, certainty.ctypes.data, C.byref(d), float(sigma),
+            int(axis_xyz), out.ctypes.data, MEM_HOST))
         return out
 
     def emphysema_features(self, image, mask, sigmas, spacing=(1.0, 1.0, 1.0),

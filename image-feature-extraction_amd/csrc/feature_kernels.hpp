@@ -578,4 +578,21 @@ __global__ __launch_bounds__(256) void divide_kernel(const float *__restrict__ a
   }
 }
 
+// Row f4: ({a_x*cT}{a*c} - {a_x*c}{a*cT}) / {a*c}^2, the differential normalized convolution
+// sketched at NormalizedGaussianConvolutionImageFilter.h:28-44, in float as written, scaled
+// to physical units; a zero denominator gives the Div functor's max().
+__global__ __launch_bounds__(256) void diffconv_kernel(const float *__restrict__ g_ct,
+                                                       const float *__restrict__ g_c,
+                                                       const float *__restrict__ gx_ct,
+                                                       const float *__restrict__ gx_c, float inv_sp,
+                                                       float *__restrict__ outv, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float den = g_c[i] * g_c[i];
+    const float num = gx_ct[i] * g_c[i] - gx_c[i] * g_ct[i];
+    outv[i] = den != 0.0f ? (num / den) * inv_sp : FLT_MAX;
+  }
+}
+
 }  // namespace ife

@@ -245,6 +245,90 @@ int gauss_coeffs(double sigma, double spacing, IirCoef *c) {
   return 0;
 }
 
+// Orders 1 and 2 of the same routine (row f4; the reference only sketches their use,
+// NormalizedGaussianConvolutionImageFilter.h:28-44): per-order constants of the exponential
+// series, normalisation to a unit response on a unit ramp / unit parabola in pixel units,
+// and the antisymmetric form of the anticausal coefficients for the first order.
+void n_coefficients(double sd, double A1, double B1, double W1, double L1, double A2, double B2,
+                    double W2, double L2, double &N0, double &N1, double &N2, double &N3, double &SN,
+                    double &DN, double &EN) {
+  const double Sin1 = std::sin(W1 / sd), Sin2 = std::sin(W2 / sd);
+  const double Cos1 = std::cos(W1 / sd), Cos2 = std::cos(W2 / sd);
+  const double Exp1 = std::exp(L1 / sd), Exp2 = std::exp(L2 / sd);
+  N0 = A1 + A2;
+  N1 = Exp2 * (B2 * Sin2 - (A2 + 2 * A1) * Cos2);
+  N1 += Exp1 * (B1 * Sin1 - (A1 + 2 * A2) * Cos1);
+  N2 = (A1 + A2) * Cos2 * Cos1;
+  N2 -= B1 * Cos2 * Sin1 + B2 * Cos1 * Sin2;
+  N2 *= 2 * Exp1 * Exp2;
+  N2 += A2 * Exp1 * Exp1 + A1 * Exp2 * Exp2;
+  N3 = Exp2 * Exp1 * Exp1 * (B2 * Sin2 - A2 * Cos2);
+  N3 += Exp1 * Exp2 * Exp2 * (B1 * Sin1 - A1 * Cos1);
+  SN = N0 + N1 + N2 + N3;
+  DN = N1 + 2 * N2 + 3 * N3;
+  EN = N1 + 4 * N2 + 9 * N3;
+}
+int gauss_coeffs_order(double sigma, double spacing, int order, IirCoef *c) {
+  if (order == 0) return gauss_coeffs(sigma, spacing, c);
+  const double A1[3] = {1.3530, -0.6724, -1.3563}, B1[3] = {1.8151, -3.4327, 5.2318};
+  const double A2[3] = {-0.3531, 0.6724, 0.3446}, B2[3] = {0.0902, 0.6100, -2.2355};
+  const double W1 = 0.6681, L1 = -1.3932, W2 = 2.0787, L2 = -1.3732;
+  if (order != 1 && order != 2) return -1;
+  double direction = 1.0;
+  if (spacing < 0.0) { direction = -1.0; spacing = -spacing; }
+  if (spacing < 1e-8) return -1;
+  const double sd = sigma / spacing;
+  {
+    const double Cos1 = std::cos(W1 / sd), Cos2 = std::cos(W2 / sd);
+    const double Exp1 = std::exp(L1 / sd), Exp2 = std::exp(L2 / sd);
+    c->D4 = Exp1 * Exp1 * Exp2 * Exp2;
+    c->D3 = -2 * Cos1 * Exp1 * Exp2 * Exp2;
+    c->D3 += -2 * Cos2 * Exp2 * Exp1 * Exp1;
+    c->D2 = 4 * Cos2 * Cos1 * Exp1 * Exp2;
+    c->D2 += Exp1 * Exp1 + Exp2 * Exp2;
+    c->D1 = -2 * (Exp2 * Cos2 + Exp1 * Cos1);
+  }
+  const double SD = 1.0 + c->D1 + c->D2 + c->D3 + c->D4;
+  const double DD = c->D1 + 2 * c->D2 + 3 * c->D3 + 4 * c->D4;
+  const double ED = c->D1 + 4 * c->D2 + 9 * c->D3 + 16 * c->D4;
+  bool symmetric;
+  if (order == 1) {
+    double SN, DN, EN;
+    n_coefficients(sd, A1[1], B1[1], W1, L1, A2[1], B2[1], W2, L2, c->N0, c->N1, c->N2, c->N3, SN, DN, EN);
+    double alpha1 = 2 * (SN * DD - DN * SD) / (SD * SD);
+    alpha1 *= direction;
+    c->N0 *= 1.0 / alpha1; c->N1 *= 1.0 / alpha1; c->N2 *= 1.0 / alpha1; c->N3 *= 1.0 / alpha1;
+    symmetric = false;
+  } else {
+    double N0_0, N1_0, N2_0, N3_0, N0_2, N1_2, N2_2, N3_2, SN0, DN0, EN0, SN2, DN2, EN2;
+    n_coefficients(sd, A1[0], B1[0], W1, L1, A2[0], B2[0], W2, L2, N0_0, N1_0, N2_0, N3_0, SN0, DN0, EN0);
+    n_coefficients(sd, A1[2], B1[2], W1, L1, A2[2], B2[2], W2, L2, N0_2, N1_2, N2_2, N3_2, SN2, DN2, EN2);
+    const double beta = -(2 * SN2 - SD * N0_2) / (2 * SN0 - SD * N0_0);
+    const double N0 = N0_2 + beta * N0_0, N1 = N1_2 + beta * N1_0;
+    const double N2 = N2_2 + beta * N2_0, N3 = N3_2 + beta * N3_0;
+    const double SN = SN2 + beta * SN0, DN = DN2 + beta * DN0, EN = EN2 + beta * EN0;
+    const double alpha2 = (EN * SD * SD - ED * SN * SD - 2 * DN * DD * SD + 2 * DD * DD * SN) / (SD * SD * SD);
+    c->N0 = N0 * (1.0 / alpha2); c->N1 = N1 * (1.0 / alpha2);
+    c->N2 = N2 * (1.0 / alpha2); c->N3 = N3 * (1.0 / alpha2);
+    symmetric = true;
+  }
+  if (symmetric) {
+    c->M1 = c->N1 - c->D1 * c->N0; c->M2 = c->N2 - c->D2 * c->N0;
+    c->M3 = c->N3 - c->D3 * c->N0; c->M4 = -c->D4 * c->N0;
+  } else {
+    c->M1 = -(c->N1 - c->D1 * c->N0); c->M2 = -(c->N2 - c->D2 * c->N0);
+    c->M3 = -(c->N3 - c->D3 * c->N0); c->M4 = c->D4 * c->N0;
+  }
+  const double SN2 = c->N0 + c->N1 + c->N2 + c->N3;
+  const double SM2 = c->M1 + c->M2 + c->M3 + c->M4;
+  const double SD2 = 1.0 + c->D1 + c->D2 + c->D3 + c->D4;
+  c->BN1 = c->D1 * SN2 / SD2; c->BN2 = c->D2 * SN2 / SD2;
+  c->BN3 = c->D3 * SN2 / SD2; c->BN4 = c->D4 * SN2 / SD2;
+  c->BM1 = c->D1 * SM2 / SD2; c->BM2 = c->D2 * SM2 / SD2;
+  c->BM3 = c->D3 * SM2 / SD2; c->BM4 = c->D4 * SM2 / SD2;
+  return 0;
+}
+
 // [ITK-upstream] DerivativeOperator coefficients after FlipAxes + ScaleCoefficients:
 // order 1 -> {-0.5, 0, 0.5} * s ; order 2 -> {1, -2, 1} * s  (s = 1/spacing, or
 // 1/spacing^2 for order 2 with IFE_OPT_DSCALE_MODE=1).
@@ -311,7 +395,7 @@ int ensure_slots(ife_ctx *ctx, const ife_volume_desc *v, int nslots) {
 // (jobs = numerator / denominator of up to three scales), each with its own sigma.
 int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
                const float *const *in, float *const *out, const double *sigma,
-               int in_y_chunks = 1) {
+               int in_y_chunks = 1, const int *order = nullptr /* per job: 0 (default), 1, 2 */) {
   if (njobs < 1 || njobs > IIR_MAX_JOBS) return fail(ctx, IFE_E_ARG, "bad job count %d", njobs);
   IirGeom g = geom_for_axis(v, axis);
   if (in_y_chunks > 1) {
@@ -339,7 +423,7 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
     jobs.j[j].out = out[j];
     jobs.j[j].ck_y = (double *)ctx->ck_y[j].p;
     jobs.j[j].ck_x = (float *)ctx->ck_x[j].p;
-    if (gauss_coeffs(sigma[j], sp, &jobs.j[j].c))
+    if (gauss_coeffs_order(sigma[j], sp, order ? order[j] : 0, &jobs.j[j].c))
       return fail(ctx, IFE_E_ARG, "spacing is suspiciously small");
   }
   g.njobs = njobs;
@@ -884,6 +968,58 @@ int ife_normalized_gaussian_convolution(ife_ctx *ctx, const float *image,
     ProfScope ps(ctx, KK_DIVIDE);
     hipLaunchKernelGGL(divide_kernel, dim3(2048), dim3(256), 0, ctx->stream, num, den,
                        (float *)dO, (int64_t)n);
+    IFE_HIP(ctx, hipGetLastError());
+  }
+  return stage_out_end(ctx, mem, out, n * 4);
+}
+
+// ---- f4: differential normalized convolution ------------------------------------------
+int ife_differential_normalized_convolution(ife_ctx *ctx, const float *image,
+                                            const float *certainty, const ife_volume_desc *vol,
+                                            double sigma, int axis, float *out, int mem) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_vol(ctx, vol, true))) return rc;
+  if (mem != IFE_MEM_HOST && mem != IFE_MEM_DEVICE) return fail(ctx, IFE_E_ARG, "bad mem");
+  if (!image || !certainty || !out) return fail(ctx, IFE_E_ARG, "null pointer");
+  if (!(sigma > 0.0)) return fail(ctx, IFE_E_ARG, "sigma must be positive");
+  if (axis < 0 || axis > 2) return fail(ctx, IFE_E_ARG, "axis must be 0 (x), 1 (y) or 2 (z)");
+  if ((rc = ensure_slots(ctx, vol, 2))) return rc;
+  const size_t n = (size_t)(vol->nx * vol->ny * vol->nz);
+  const void *dI, *dC;
+  void *dO;
+  if ((rc = stage_in(ctx, mem, image, n * 4, ctx->st_img, &dI))) return rc;
+  if ((rc = stage_in(ctx, mem, certainty, n * 4, ctx->st_aux, &dC))) return rc;
+  if ((rc = stage_out_begin(ctx, mem, out, n * 4, &dO))) return rc;
+  if ((rc = ensure(ctx, ctx->pre[0], n * sizeof(float)))) return rc;
+  float *tc = (float *)ctx->pre[0].p;
+  if ((rc = launch_prep<float, float>(ctx, (const float *)dI, (const float *)dC, tc, nullptr, (int64_t)n)))
+    return rc;
+  // four fields through the three axis passes in one launch each: a*cT, a*c, a_x*cT, a_x*c
+  // (slot 0: the 0th-order pair, slot 1: the pair differentiated along `axis`)
+  const float *in[4];
+  float *o[4];
+  const double sg[4] = {sigma, sigma, sigma, sigma};
+  const int pass_axis[3] = {2, 0, 1};  // SmoothingRecursiveGaussianImageFilter: z, x, y
+  for (int p = 0; p < 3 && !rc; ++p) {
+    const int a = pass_axis[p];
+    const int ord[4] = {0, 0, a == axis ? 1 : 0, a == axis ? 1 : 0};
+    for (int j = 0; j < 4; ++j) {
+      const int slot = j / 2, f = j % 2;
+      const int src = (p % 2 == 0) ? 1 : 0, dst = (p % 2 == 0) ? 0 : 1;  // ping-pong: ->0, ->1, ->0
+      in[j] = p == 0 ? (f == 0 ? tc : (const float *)dC) : (const float *)ctx->fld[slot][2 * f + src].p;
+      o[j] = (float *)ctx->fld[slot][2 * f + dst].p;
+    }
+    rc = launch_iir(ctx, vol, a, 4, in, o, sg, 1, ord);
+  }
+  if (rc) return rc;
+  {
+    ProfScope ps(ctx, KK_DIVIDE);
+    hipLaunchKernelGGL(diffconv_kernel, dim3(2048), dim3(256), 0, ctx->stream,
+                       (const float *)ctx->fld[0][0].p, (const float *)ctx->fld[0][2].p,
+                       (const float *)ctx->fld[1][0].p, (const float *)ctx->fld[1][2].p,
+                       (float)(1.0 / (axis == 0 ? vol->sx : axis == 1 ? vol->sy : vol->sz)), (float *)dO,
+                       (int64_t)n);
     IFE_HIP(ctx, hipGetLastError());
   }
   return stage_out_end(ctx, mem, out, n * 4);

@@ -1,6 +1,9 @@
 // NormalizedGaussianConvolutionImageFilter.h -- host mirror of
 // include/ife/Filters/NormalizedGaussianConvolutionImageFilter.h:86-93 (.hxx:40-63):
 // U = G_sigma(T*c) / G_sigma(c), forwarded to ife_normalized_gaussian_convolution.
+// One addition: SetDerivativeDirection(0|1|2) selects the differential form the reference
+// sketches in its header comment (.h:28-44), d/dx_axis of U with the derivative taken on the
+// Gaussian (ife_differential_normalized_convolution); -1 (default) is the reference's filter.
 #ifndef NormalizedGaussianConvolutionImageFilter_h
 #define NormalizedGaussianConvolutionImageFilter_h
 
@@ -19,6 +22,8 @@ class NormalizedGaussianConvolutionImageFilter {
   void SetInputCertainty(const TImage *c) { cert_ = c; dirty_ = true; }
   void SetSigma(ScalarRealType s) { if (s != sigma_) { sigma_ = s; dirty_ = true; } }
   ScalarRealType GetSigma() const { return sigma_; }
+  void SetDerivativeDirection(int axis) { if (axis != daxis_) { daxis_ = axis; dirty_ = true; } }
+  int GetDerivativeDirection() const { return daxis_; }
   void Update() {
     if (!dirty_ && out_.IsNotNull()) return;
     if (!image_ || !cert_)
@@ -30,10 +35,16 @@ class NormalizedGaussianConvolutionImageFilter {
     if (out_.IsNull()) out_ = TImage::New();
     out_->CopyInformation(image_);
     out_->Allocate();
-    e.check(ife_normalized_gaussian_convolution(e.ctx(), image_->GetBufferPointer(),
-                                                cert_->GetBufferPointer(), &d, sigma_,
-                                                out_->GetBufferPointer(), IFE_MEM_HOST),
-            "NormalizedGaussianConvolutionImageFilter");
+    if (daxis_ >= 0)
+      e.check(ife_differential_normalized_convolution(e.ctx(), image_->GetBufferPointer(),
+                                                      cert_->GetBufferPointer(), &d, sigma_, daxis_,
+                                                      out_->GetBufferPointer(), IFE_MEM_HOST),
+              "NormalizedGaussianConvolutionImageFilter");
+    else
+      e.check(ife_normalized_gaussian_convolution(e.ctx(), image_->GetBufferPointer(),
+                                                  cert_->GetBufferPointer(), &d, sigma_,
+                                                  out_->GetBufferPointer(), IFE_MEM_HOST),
+              "NormalizedGaussianConvolutionImageFilter");
     dirty_ = false;
   }
   void UpdateLargestPossibleRegion() { Update(); }
@@ -45,6 +56,7 @@ class NormalizedGaussianConvolutionImageFilter {
  private:
   const TImage *image_ = nullptr, *cert_ = nullptr;
   ScalarRealType sigma_ = 1.0;  // .hxx:18
+  int daxis_ = -1;
   bool dirty_ = true;
   typename TImage::Pointer out_;
 };

@@ -160,6 +160,18 @@ int ife_normalized_gaussian_convolution(ife_ctx *ctx, const float *image,
                                         const float *certainty, const ife_volume_desc *vol,
                                         double sigma, float *out, int mem);
 
+/* ---- f4: differential normalized convolution ---------------------------------------- */
+
+/* The derivative form the reference sketches but does not implement
+ * (include/ife/Filters/NormalizedGaussianConvolutionImageFilter.h:28-44):
+ *   out = ({a_x*cT}{a*c} - {a_x*c}{a*cT}) / {a*c}^2  / spacing[axis]
+ * a = the recursive Gaussian of ife_normalized_gaussian_convolution (axes z, x, y), a_x = the
+ * same with ITK's FirstOrder recursive Gaussian along `axis` (0 = x, 1 = y, 2 = z; pixel units,
+ * hence the division by the spacing).  Float arithmetic as written; {a*c}^2 == 0 -> FLT_MAX. */
+int ife_differential_normalized_convolution(ife_ctx *ctx, const float *image,
+                                            const float *certainty, const ife_volume_desc *vol,
+                                            double sigma, int axis, float *out, int mem);
+
 /* ---- a5 + a9: ImageToEmphysemaFeaturesFilter, one execution per scale ------------ */
 
 /* SetInputImage + SetInputMask + for each sigma {SetSigma; Update; GetOutput}

@@ -256,6 +256,105 @@ void ife_or_iir_line(const double *data, double *outs, double *s, int64_t ln,
   for (int64_t i = 0; i < ln; i++) outs[i] += s[i];
 }
 
+/* ------------------------------------------------------------------------- */
+/* Row f4.  [ITK-upstream, parity unpinned] itk::RecursiveGaussianImageFilter::SetUp for   */
+/* the three orders (ZeroOrder above is the order-0 case of this).  Constants of the       */
+/* exponential series per order, ComputeNCoefficients / ComputeDCoefficients, the         */
+/* normalisations alpha0 / alpha1 / alpha2 (unit response to a constant, a unit ramp, a    */
+/* unit parabola, in PIXEL units) and ComputeRemainingCoefficients(symmetric): the first   */
+/* order is antisymmetric (M = -(N - D N0), M4 = +D4 N0).  NormalizeAcrossScale off.       */
+/* The reference never instantiates orders 1 and 2: it only sketches the differential      */
+/* normalized convolution in a comment (NormalizedGaussianConvolutionImageFilter.h:28-44). */
+/* ------------------------------------------------------------------------- */
+static void n_coefficients(double sigmad, double A1, double B1, double W1, double L1, double A2,
+                           double B2, double W2, double L2, double *N0, double *N1, double *N2,
+                           double *N3, double *SN, double *DN, double *EN) {
+  const double Sin1 = sin(W1 / sigmad), Sin2 = sin(W2 / sigmad);
+  const double Cos1 = cos(W1 / sigmad), Cos2 = cos(W2 / sigmad);
+  const double Exp1 = exp(L1 / sigmad), Exp2 = exp(L2 / sigmad);
+  *N0 = A1 + A2;
+  *N1 = Exp2 * (B2 * Sin2 - (A2 + 2 * A1) * Cos2);
+  *N1 += Exp1 * (B1 * Sin1 - (A1 + 2 * A2) * Cos1);
+  *N2 = (A1 + A2) * Cos2 * Cos1;
+  *N2 -= B1 * Cos2 * Sin1 + B2 * Cos1 * Sin2;
+  *N2 *= 2 * Exp1 * Exp2;
+  *N2 += A2 * Exp1 * Exp1 + A1 * Exp2 * Exp2;
+  *N3 = Exp2 * Exp1 * Exp1 * (B2 * Sin2 - A2 * Cos2);
+  *N3 += Exp1 * Exp2 * Exp2 * (B1 * Sin1 - A1 * Cos1);
+  *SN = *N0 + *N1 + *N2 + *N3;
+  *DN = *N1 + 2 * *N2 + 3 * *N3;
+  *EN = *N1 + 4 * *N2 + 9 * *N3;
+}
+
+int ife_or_gauss_coeffs_order(double sigma, double spacing, int order, ife_or_gauss_coeffs *c) {
+  const double A1[3] = {1.3530, -0.6724, -1.3563}, B1[3] = {1.8151, -3.4327, 5.2318};
+  const double A2[3] = {-0.3531, 0.6724, 0.3446}, B2[3] = {0.0902, 0.6100, -2.2355};
+  const double W1 = 0.6681, L1 = -1.3932, W2 = 2.0787, L2 = -1.3732;
+  if (order == 0) return ife_or_gauss_coeffs_zero_order(sigma, spacing, c);
+  if (order != 1 && order != 2) return -1;
+  double direction = 1.0;
+  if (spacing < 0.0) { direction = -1.0; spacing = -spacing; }
+  if (spacing < 1e-8) return -1;
+  const double sigmad = sigma / spacing;
+  {
+    const double Cos1 = cos(W1 / sigmad), Cos2 = cos(W2 / sigmad);
+    const double Exp1 = exp(L1 / sigmad), Exp2 = exp(L2 / sigmad);
+    c->D4 = Exp1 * Exp1 * Exp2 * Exp2;
+    c->D3 = -2 * Cos1 * Exp1 * Exp2 * Exp2;
+    c->D3 += -2 * Cos2 * Exp2 * Exp1 * Exp1;
+    c->D2 = 4 * Cos2 * Cos1 * Exp1 * Exp2;
+    c->D2 += Exp1 * Exp1 + Exp2 * Exp2;
+    c->D1 = -2 * (Exp2 * Cos2 + Exp1 * Cos1);
+  }
+  const double SD = 1.0 + c->D1 + c->D2 + c->D3 + c->D4;
+  const double DD = c->D1 + 2 * c->D2 + 3 * c->D3 + 4 * c->D4;
+  const double ED = c->D1 + 4 * c->D2 + 9 * c->D3 + 16 * c->D4;
+  int symmetric;
+  if (order == 1) {
+    double SN, DN, EN;
+    n_coefficients(sigmad, A1[1], B1[1], W1, L1, A2[1], B2[1], W2, L2, &c->N0, &c->N1, &c->N2,
+                   &c->N3, &SN, &DN, &EN);
+    double alpha1 = 2 * (SN * DD - DN * SD) / (SD * SD);
+    alpha1 *= direction;
+    c->N0 *= 1.0 / alpha1; c->N1 *= 1.0 / alpha1; c->N2 *= 1.0 / alpha1; c->N3 *= 1.0 / alpha1;
+    symmetric = 0;
+  } else {
+    double N0_0, N1_0, N2_0, N3_0, N0_2, N1_2, N2_2, N3_2, SN0, DN0, EN0, SN2, DN2, EN2;
+    n_coefficients(sigmad, A1[0], B1[0], W1, L1, A2[0], B2[0], W2, L2, &N0_0, &N1_0, &N2_0, &N3_0,
+                   &SN0, &DN0, &EN0);
+    n_coefficients(sigmad, A1[2], B1[2], W1, L1, A2[2], B2[2], W2, L2, &N0_2, &N1_2, &N2_2, &N3_2,
+                   &SN2, &DN2, &EN2);
+    const double beta = -(2 * SN2 - SD * N0_2) / (2 * SN0 - SD * N0_0);
+    const double N0 = N0_2 + beta * N0_0, N1 = N1_2 + beta * N1_0;
+    const double N2 = N2_2 + beta * N2_0, N3 = N3_2 + beta * N3_0;
+    const double SN = SN2 + beta * SN0, DN = DN2 + beta * DN0, EN = EN2 + beta * EN0;
+    const double alpha2 = (EN * SD * SD - ED * SN * SD - 2 * DN * DD * SD + 2 * DD * DD * SN) /
+                          (SD * SD * SD);
+    c->N0 = N0 * (1.0 / alpha2); c->N1 = N1 * (1.0 / alpha2);
+    c->N2 = N2 * (1.0 / alpha2); c->N3 = N3 * (1.0 / alpha2);
+    symmetric = 1;
+  }
+  if (symmetric) {
+    c->M1 = c->N1 - c->D1 * c->N0;
+    c->M2 = c->N2 - c->D2 * c->N0;
+    c->M3 = c->N3 - c->D3 * c->N0;
+    c->M4 = -c->D4 * c->N0;
+  } else {
+    c->M1 = -(c->N1 - c->D1 * c->N0);
+    c->M2 = -(c->N2 - c->D2 * c->N0);
+    c->M3 = -(c->N3 - c->D3 * c->N0);
+    c->M4 = c->D4 * c->N0;
+  }
+  const double SN2b = c->N0 + c->N1 + c->N2 + c->N3;
+  const double SM2b = c->M1 + c->M2 + c->M3 + c->M4;
+  const double SD2b = 1.0 + c->D1 + c->D2 + c->D3 + c->D4;
+  c->BN1 = c->D1 * SN2b / SD2b; c->BN2 = c->D2 * SN2b / SD2b;
+  c->BN3 = c->D3 * SN2b / SD2b; c->BN4 = c->D4 * SN2b / SD2b;
+  c->BM1 = c->D1 * SM2b / SD2b; c->BM2 = c->D2 * SM2b / SD2b;
+  c->BM3 = c->D3 * SM2b / SD2b; c->BM4 = c->D4 * SM2b / SD2b;
+  return 0;
+}
+
 static int64_t axis_len(const ife_or_dims *d, int a) { return a == 0 ? d->nx : a == 1 ? d->ny : d->nz; }
 static double axis_sp(const ife_or_dims *d, int a) { return a == 0 ? d->sx : a == 1 ? d->sy : d->sz; }
 static int64_t axis_stride(const ife_or_dims *d, int a) {
@@ -266,10 +365,15 @@ static int64_t axis_stride(const ife_or_dims *d, int a) {
  * double, FilterDataArray, cast each sample back to the (float) output pixel type. */
 int ife_or_recursive_gaussian_axis(const float *in, float *out, const ife_or_dims *d, int axis,
                                    double sigma) {
+  return ife_or_recursive_gaussian_axis_order(in, out, d, axis, sigma, 0);
+}
+
+int ife_or_recursive_gaussian_axis_order(const float *in, float *out, const ife_or_dims *d, int axis,
+                                         double sigma, int order) {
   const int64_t ln = axis_len(d, axis);
   if (ln < 4) return -2;
   ife_or_gauss_coeffs c;
-  if (ife_or_gauss_coeffs_zero_order(sigma, axis_sp(d, axis), &c)) return -1;
+  if (ife_or_gauss_coeffs_order(sigma, axis_sp(d, axis), order, &c)) return -1;
   const int64_t st = axis_stride(d, axis);
   const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
   const int64_t n1 = axis_len(d, a1), n2 = axis_len(d, a2);
@@ -336,6 +440,62 @@ int ife_or_normalized_gaussian_convolution(const float *image, const float *cert
     for (int64_t i = 0; i < n; ++i) out[i] = (g2[i] != 0.0f) ? g1[i] / g2[i] : FLT_MAX;
   }
   free(tc); free(g1); free(g2);
+  return rc;
+}
+
+/* Row f4: the differential normalized convolution the reference sketches at
+ * NormalizedGaussianConvolutionImageFilter.h:28-44:
+ *   d/dx [{a*cT}/{a*c}] = ({a_x*cT}{a*c} - {a_x*c}{a*cT}) / {a*c}^2
+ * with a the Gaussian of the 0th-order filter and a_x the same separable filter with the
+ * FirstOrder recursive Gaussian along `axis` (the axes run Z, X, Y like
+ * SmoothingRecursiveGaussianImageFilter; float images between the passes).  The first-order
+ * filter answers in pixel units; dividing by the spacing of the axis gives physical units
+ * (as itk::GradientRecursiveGaussianImageFilter does).  Float arithmetic, evaluated as
+ * written; a zero denominator gives NumericTraits<float>::max() like the Div functor. */
+static int smooth_with_order(const float *in, float *out, const ife_or_dims *d, double sigma,
+                             int deriv_axis) {
+  const int64_t n = d->nx * d->ny * d->nz;
+  float *tmp = (float *)malloc(sizeof(float) * (size_t)n);
+  if (!tmp) return -3;
+  int rc = ife_or_recursive_gaussian_axis_order(in, tmp, d, 2, sigma, deriv_axis == 2);
+  if (!rc) rc = ife_or_recursive_gaussian_axis_order(tmp, out, d, 0, sigma, deriv_axis == 0);
+  if (!rc) {
+    memcpy(tmp, out, sizeof(float) * (size_t)n);
+    rc = ife_or_recursive_gaussian_axis_order(tmp, out, d, 1, sigma, deriv_axis == 1);
+  }
+  free(tmp);
+  return rc;
+}
+
+int ife_or_differential_normalized_convolution(const float *image, const float *certainty,
+                                               float *out, const ife_or_dims *d, double sigma,
+                                               int axis) {
+  if (axis < 0 || axis > 2) return -1;
+  const int64_t n = d->nx * d->ny * d->nz;
+  float *tc = (float *)malloc(sizeof(float) * (size_t)n);
+  float *g[4] = {0, 0, 0, 0};
+  int rc = tc ? 0 : -3;
+  for (int k = 0; k < 4 && !rc; ++k)
+    if (!(g[k] = (float *)malloc(sizeof(float) * (size_t)n))) rc = -3;
+  if (!rc) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) tc[i] = image[i] * certainty[i];
+    rc = smooth_with_order(tc, g[0], d, sigma, -1);                 /* a * cT   */
+  }
+  if (!rc) rc = smooth_with_order(certainty, g[1], d, sigma, -1);   /* a * c    */
+  if (!rc) rc = smooth_with_order(tc, g[2], d, sigma, axis);        /* a_x * cT */
+  if (!rc) rc = smooth_with_order(certainty, g[3], d, sigma, axis); /* a_x * c  */
+  if (!rc) {
+    const float inv_sp = (float)(1.0 / axis_sp(d, axis));
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+      const float den = g[1][i] * g[1][i];
+      const float num = g[2][i] * g[1][i] - g[3][i] * g[0][i];
+      out[i] = (den != 0.0f) ? (num / den) * inv_sp : FLT_MAX;
+    }
+  }
+  free(tc);
+  for (int k = 0; k < 4; ++k) free(g[k]);
   return rc;
 }
 

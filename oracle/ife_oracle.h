@@ -67,6 +67,13 @@ void ife_or_eig3_batch_f64(const double *A6, int64_t n, double *ev3);
 
 /* a4 pieces: itk::RecursiveGaussianImageFilter (ZeroOrder) */
 int ife_or_gauss_coeffs_zero_order(double sigma, double spacing, ife_or_gauss_coeffs *c);
+/* orders 0, 1, 2 of itk::RecursiveGaussianImageFilter::SetUp (row f4) */
+int ife_or_gauss_coeffs_order(double sigma, double spacing, int order, ife_or_gauss_coeffs *c);
+int ife_or_recursive_gaussian_axis_order(const float *in, float *out, const ife_or_dims *d,
+                                         int axis, double sigma, int order);
+int ife_or_differential_normalized_convolution(const float *image, const float *certainty,
+                                               float *out, const ife_or_dims *d, double sigma,
+                                               int axis);
 void ife_or_iir_line(const double *data, double *outs, double *scratch, int64_t ln,
                      const ife_or_gauss_coeffs *c);
 int ife_or_recursive_gaussian_axis(const float *in, float *out, const ife_or_dims *d,

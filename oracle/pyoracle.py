@@ -97,6 +97,35 @@ def gauss_coeffs(sigma, spacing=1.0):
     return c
 
 
+def gauss_coeffs_order(sigma, spacing=1.0, order=0):
+    """Orders 0, 1, 2 of itk::RecursiveGaussianImageFilter::SetUp (row f4)."""
+    c = GaussCoeffs()
+    _chk(lib().ife_or_gauss_coeffs_order(C.c_double(sigma), C.c_double(spacing), C.c_int(order),
+                                   C.byref(c)), "gauss_coeffs")
+    return c
+
+
+def iir_line_order(data, sigma, spacing=1.0, order=0):
+    data = np.ascontiguousarray(data, np.float64)
+    c = gauss_coeffs_order(sigma, spacing, order)
+    out = np.empty_like(data)
+    scr = np.empty_like(data)
+    lib().ife_or_iir_line(_p(data, C.c_double), _p(out, C.c_double), _p(scr, C.c_double),
+                          C.c_int64(data.size), C.byref(c))
+    return out
+
+
+def differential_normalized_convolution(image, certainty, sigma, axis_xyz, spacing=(1.0, 1.0, 1.0)):
+    image = np.ascontiguousarray(image, np.float32)
+    certainty = np.ascontiguousarray(certainty, np.float32)
+    out = np.empty_like(image)
+    d = _dims(image.shape, spacing)
+    _chk(lib().ife_or_differential_normalized_convolution(
+        _p(image, C.c_float), _p(certainty, C.c_float), _p(out, C.c_float), C.byref(d),
+        C.c_double(sigma), C.c_int(axis_xyz)), "differential normconv")
+    return out
+
+
 def iir_line(data, sigma, spacing=1.0):
     data = np.ascontiguousarray(data, np.float64)
     c = gauss_coeffs(sigma, spacing)

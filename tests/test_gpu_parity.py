@@ -148,6 +148,22 @@ def test_iir_block_size_is_invisible(ctx, ife, oracle, synth, block):
     np.testing.assert_array_equal(got, oracle.normalized_gaussian_convolution(img, cert, 3.0))
 
 
+@pytest.mark.parametrize("shape,sigma,spacing", [((33, 36, 40), 1.5, (1, 1, 1)),
+                                                 ((17, 8, 129), 2.5, (0.7, 0.8, 1.25)),
+                                                 ((4, 5, 70), 0.8, (1, 1, 1))])
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_differential_normalized_convolution_bit_exact(ctx, oracle, synth, shape, sigma, spacing, axis):
+    """Row f4: ITK's first-order recursive Gaussian along `axis` inside the normalized
+    convolution, on the line kernels; same bits as the oracle's restatement."""
+    img = synth.volume_f32(shape, 77)
+    cert = (synth.mask_ellipsoids(shape) > 0).astype(np.float32)
+    cert[0, 0, 0] = 1.0
+    cert += np.float32(0.25) * (np.arange(cert.size).reshape(shape) % 3 == 0)
+    got = ctx.differential_normalized_convolution(img, cert, sigma, axis, spacing)
+    ref = oracle.differential_normalized_convolution(img, cert, sigma, axis, spacing)
+    np.testing.assert_array_equal(got, ref)
+
+
 def test_zero_certainty_gives_flt_max(ctx, oracle):
     shape = (12, 12, 12)
     img = np.ones(shape, np.float32)

@@ -220,3 +220,62 @@ def test_fd_snapshot(oracle):
     np.testing.assert_array_equal(oracle.fd_hessian_features(z["image"], z["mask"]), z["features"])
     np.testing.assert_array_equal(oracle.hessian3d(z["image"]), z["hessian"])
     np.testing.assert_array_equal(oracle.gradient_magnitude(z["image"]), z["gradmag"])
+
+
+# ---------------------------------------------------------------------------------
+# Row f4: first / second order recursive Gaussian and the differential normalized convolution
+# (no reference implementation exists: NormalizedGaussianConvolutionImageFilter.h:28-44 is a
+# comment; these pin the restated ITK coefficient sets by the properties ITK normalises them to)
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("sigma", [1.0, 2.0, 4.0])
+def test_derivative_filters_have_their_defining_responses(oracle, sigma):
+    x = np.arange(300, dtype=np.float64)
+    mid = slice(100, 200)
+    d1 = oracle.iir_line_order(3.0 * x + 5.0, sigma, 1.0, 1)
+    assert np.abs(d1[mid] - 3.0).max() < 1e-10            # unit response to a unit ramp
+    d2 = oracle.iir_line_order(0.5 * x * x, sigma, 1.0, 2)
+    assert np.abs(d2[mid] - 1.0).max() < 1e-8             # unit response to a unit parabola
+    assert np.abs(oracle.iir_line_order(np.full(300, 7.0), sigma, 1.0, 1)).max() < 1e-12
+    assert np.abs(oracle.iir_line_order(np.full(300, 7.0), sigma, 1.0, 2)[mid]).max() < 1e-10
+    # impulse responses: antisymmetric / symmetric, close to the sampled Gaussian derivatives
+    imp = np.zeros(301)
+    imp[150] = 1.0
+    k = np.arange(-150, 151, dtype=np.float64)
+    g = np.exp(-k * k / (2 * sigma * sigma)) / (sigma * np.sqrt(2 * np.pi))
+    h1 = oracle.iir_line_order(imp, sigma, 1.0, 1)
+    h2 = oracle.iir_line_order(imp, sigma, 1.0, 2)
+    assert np.abs(h1 + h1[::-1]).max() < 1e-12 and np.abs(h2 - h2[::-1]).max() < 1e-12
+    if sigma >= 2.0:
+        assert np.abs(h1 - (-k / sigma ** 2) * g).max() < 0.005 * np.abs(k / sigma ** 2 * g).max()
+        assert np.abs(h2 - (k * k / sigma ** 4 - 1 / sigma ** 2) * g).max() < 0.02 / sigma ** 3
+    # spacing: sigma in physical units, response still per PIXEL (ITK's gradient filter divides later)
+    d1s = oracle.iir_line_order(3.0 * x, 2.0 * sigma, 2.0, 1)
+    assert np.abs(d1s[mid] - 3.0).max() < 1e-10
+
+
+def test_differential_normalized_convolution_properties(oracle):
+    rng = np.random.default_rng(4)
+    shape = (20, 24, 28)
+    z, y, x = np.meshgrid(*[np.arange(n, dtype=np.float32) for n in shape], indexing="ij")
+    ramp = (2.0 * x - 3.0 * y + 0.5 * z).astype(np.float32)
+    ones = np.ones(shape, np.float32)
+    sp = (0.5, 2.0, 1.0)
+    inner = (slice(8, 12), slice(9, 15), slice(10, 18))
+    for axis, slope in ((0, 2.0 / 0.5), (1, -3.0 / 2.0), (2, 0.5 / 1.0)):   # physical units
+        d = oracle.differential_normalized_convolution(ramp, ones, 1.5, axis, sp)
+        # (the volume is only a few sigma wide: the replicated border bends the ramp a little)
+        assert np.abs(d[inner] - slope).max() < 1e-2 * abs(slope)
+    # full certainty: equals the first-order recursive Gaussian of the image itself / spacing
+    img = rng.standard_normal(shape).astype(np.float32)
+    d = oracle.differential_normalized_convolution(img, ones, 2.0, 0)
+    smooth = oracle.differential_normalized_convolution(img, ones, 2.0, 0)
+    np.testing.assert_array_equal(d, smooth)
+    # a scaled certainty cancels; a hole in the certainty changes the result only nearby
+    d_half = oracle.differential_normalized_convolution(img, 0.5 * ones, 2.0, 0)
+    assert np.abs(d_half - d).max() < 1e-4
+    holed = ones.copy()
+    holed[2:4, 2:4, 2:4] = 0
+    d_h = oracle.differential_normalized_convolution(img, holed, 1.0, 1)
+    d_f = oracle.differential_normalized_convolution(img, ones, 1.0, 1)
+    assert np.abs(d_h - d_f)[12:, 14:, 16:].max() < 1e-5 and np.abs(d_h - d_f).max() > 1e-3
+    assert (oracle.differential_normalized_convolution(img, 0 * ones, 1.0, 2) == np.finfo(np.float32).max).all()
