@@ -468,7 +468,8 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
 constexpr int ZSLAB_K = 12;  // register block of the slab kernels (fixes the checkpoint layout)
 int64_t zslab_pairs(int64_t n) { return ((n + ZSLAB_K - 1) / ZSLAB_K + 1) / 2; }
 size_t zslab_ck_bytes(const ife_volume_desc *v) {
-  return (size_t)zslab_pairs(v->nz) * 4 * (size_t)(v->nx * v->ny) * 2 * (sizeof(double) + sizeof(float));
+  const size_t L = (size_t)(v->nx * v->ny);
+  return (size_t)zslab_pairs(v->nz) * 4 * L * 2 * sizeof(double) + 2 * 4 * L * sizeof(float);
 }
 // phase 0: causal sweep, 1: anticausal sweep, 2: combine
 int launch_zslab(ife_ctx *ctx, int phase, int njobs, const float *const *in, float *const *out,
@@ -502,7 +503,7 @@ int launch_zslab(ife_ctx *ctx, int phase, int njobs, const float *const *in, flo
     double *cy = (double *)ck[j];
     double *ay = cy + np * 4 * L;
     float *cx = (float *)(ay + np * 4 * L);
-    float *ax = cx + np * 4 * L;
+    float *ax = cx + 4 * L;
     J.cy = cy + line0; J.ay = ay + line0; J.cx = cx + line0; J.ax = ax + line0;
     const size_t rec = (size_t)nlines * 48;  // [4][nlines] doubles, then [4][nlines] floats
     if (state_in) {

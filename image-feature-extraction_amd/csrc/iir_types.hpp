@@ -65,15 +65,16 @@ struct IirJobs {
 // z1; the anticausal one enters from above with (y[z1..z1+3], x[z1..z1+3]) and leaves
 // with the record at z0.  A record is 4 doubles + 4 floats per line, struct-of-arrays:
 // y[k][line] (k = 0: nearest sample), then x[k][line].  Every pair of register blocks has
-// one causal checkpoint (the state in front of its first sample) and one anticausal
-// checkpoint (the state in front of its last sample, coming from above), so that the
-// combine kernel can rebuild both recursions of a pair from them -- the same sequential
-// arithmetic as the single-device kernel, sample for sample.
+// one causal checkpoint (the y values in front of its first sample) and one anticausal
+// checkpoint (the y values in front of its last sample, coming from above); the x history
+// of a checkpoint is re-read from the samples around the pair, that of the slab's incoming
+// states is kept once.  The combine kernel rebuilds both recursions of a pair from them --
+// the same sequential arithmetic as the single-device kernel, sample for sample.
 struct ZSlabJob {
   const float *in;
   float *out;              // combine only
-  double *cy; float *cx;   // causal checkpoints      [npairs][4][ck_stride]
-  double *ay; float *ax;   // anticausal checkpoints  [npairs][4][ck_stride]
+  double *cy, *ay;  // causal / anticausal checkpoints: the four y values, [npairs][4][ck_stride]
+  float *cx, *ax;   // x history of the incoming causal / anticausal state, [4][ck_stride]
   const double *sin_y; const float *sin_x;  // incoming state of the sweep, [4][nlines]
   double *sout_y; float *sout_x;            // outgoing state of the sweep, [4][nlines]
   IirCoef c;

@@ -261,6 +261,17 @@ class SlabEngine:
         # scale groups: their sweeps share launches and messages; the bulk phase follows them
         self.scale_groups = [list(range(s0, min(S, s0 + spi))) for s0 in range(0, S, spi)]
         self.items = [(q, g) for q in range(len(self.scale_groups)) for g in range(len(self.groups))]
+        # the bulk phase follows the chains group by group, except that everything behind the
+        # first group is merged into launches of up to `max_jobs` jobs: a one-scale launch on a
+        # thin slab fills a third of the device (64 planes: 0.122 ms per scale against 0.29 for three)
+        self.bulk_groups = [[0]]
+        for q in range(1, len(self.scale_groups)):
+            last = self.bulk_groups[-1]
+            n_sc = sum(len(self.scale_groups[k]) for k in last) + len(self.scale_groups[q])
+            if len(self.bulk_groups) > 1 and n_sc <= max_jobs:
+                last.append(q)
+            else:
+                self.bulk_groups.append([q])
         self.schedule = sweep_schedule(rank, world, len(self.items))
         f = lambda *shp: alloc(shp, "float32")
         self.src = [f(nzl, ny, nx) for _ in range(nf)]                      # tc, cf
@@ -338,9 +349,10 @@ class SlabEngine:
                     self.sent[d][i] = comm.isend_down(sout)
 
         first = 0 if has_lo else 1
-        for q, ss in enumerate(self.scale_groups):
+        for qs in self.bulk_groups:
+            ss = [s for q in qs for s in self.scale_groups[q]]
             for i, (qi, g) in enumerate(self.items):
-                if qi == q:
+                if qi in qs:
                     wait(bulk, swept[0][i])
                     wait(bulk, swept[1][i])
             sg = [self.sigmas[s] for s in ss for _ in range(nf)]
