@@ -133,13 +133,24 @@ class TorchComm:
     data through host memory (for backends that cannot take device tensors: gloo with the
     ranks of a test sharing one GPU)."""
 
-    def __init__(self, dist, rank, world, host_staging=False):
+    def __init__(self, dist, rank, world, host_staging=False, per_edge_groups=True):
         self.dist, self.rank, self.world, self.host = dist, rank, world, host_staging
         self.up, self.down, self.halo_g = [], [], []
-        for e in range(world - 1):  # collective: every rank creates every group, same order
-            self.up.append(dist.new_group([e, e + 1]))
-            self.down.append(dist.new_group([e, e + 1]))
-            self.halo_g.append(dist.new_group([e, e + 1]))
+        try:
+            if not per_edge_groups:
+                raise RuntimeError("disabled by the caller")
+            for e in range(world - 1):  # collective: every rank creates every group, same order
+                self.up.append(dist.new_group([e, e + 1]))
+                self.down.append(dist.new_group([e, e + 1]))
+                self.halo_g.append(dist.new_group([e, e + 1]))
+        except Exception as exc:  # noqa: BLE001 -- a backend without sub-groups
+            # Everything then shares the default group.  Still correct: every rank issues its
+            # transfers of one direction of an edge in the same order (chain items, then stencil
+            # planes), only a class may now queue behind another.
+            import sys
+            print("slab.TorchComm: per-edge communicators unavailable (%s); using the default group"
+                  % exc, file=sys.stderr)
+            self.up = self.down = self.halo_g = [None] * max(world - 1, 0)
 
     def _isend(self, buf, dst, group):
         if self.host:

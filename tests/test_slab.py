@@ -154,7 +154,7 @@ class OracleStages:
         out.copy_(torch.from_numpy(res))
 
 
-def _worker(rank, world, port, shape, sigmas, spacing, use_hip, bounds, line_groups, steps, spi, ret):
+def _worker(rank, world, port, shape, sigmas, spacing, use_hip, bounds, line_groups, steps, spi, edge_groups, ret):
     sys.path.insert(0, ROOT)
     os.environ["IFE_TRIG_MODE"] = "0"
     import torch
@@ -188,7 +188,8 @@ def _worker(rank, world, port, shape, sigmas, spacing, use_hip, bounds, line_gro
             pyoracle.set_threads(2)
             dev = torch.device("cpu")
             stages = OracleStages(pyoracle)
-            comm = slab.TorchComm(dist, rank, world, host_staging=False)  # the product branch
+            comm = slab.TorchComm(dist, rank, world, host_staging=False,  # the product branch
+                                  per_edge_groups=edge_groups)
         dt = {"float32": torch.float32, "uint8": torch.uint8}
         alloc = lambda shp, d: torch.empty(shp, dtype=dt[d], device=dev)
         eng = slab.SlabEngine(stages, comm, shape, spacing, sigmas, rank, world, alloc,
@@ -208,11 +209,11 @@ def _worker(rank, world, port, shape, sigmas, spacing, use_hip, bounds, line_gro
 
 
 def _run_world(world, shape, sigmas, spacing, use_hip, tmp_path, bounds=None, line_groups=None,
-               steps=1, spi=None):
+               steps=1, spi=None, edge_groups=True):
     import torch.multiprocessing as mp
     port = _free_port()
     mp.spawn(_worker, args=(world, port, shape, sigmas, spacing, use_hip, bounds, line_groups,
-                            steps, spi, str(tmp_path)), nprocs=world, join=True)
+                            steps, spi, edge_groups, str(tmp_path)), nprocs=world, join=True)
     parts = [np.load(os.path.join(str(tmp_path), "out_%d.npy" % r)) for r in range(world)]
     return np.concatenate(parts, axis=1)  # along z
 
@@ -224,15 +225,17 @@ def _whole_volume(synth, shape):
     return img, mask
 
 
-@pytest.mark.parametrize("world,shape,spacing,bounds,groups,steps,spi", [
-    (2, (16, 20, 12), (1.0, 1.0, 1.0), None, 1, 2, None),          # all scales in one item
-    (3, (19, 40, 30), (1.0, 1.0, 1.0), [0, 4, 11, 19], 3, 1, 2),   # uneven cut, 3 line groups, scales 2 + 1
-    (4, (29, 24, 40), (0.8, 1.0, 1.25), None, 2, 2, None),         # 8,7,7,7 planes, one scale per item
+@pytest.mark.parametrize("world,shape,spacing,bounds,groups,steps,spi,edge_groups", [
+    (2, (16, 20, 12), (1.0, 1.0, 1.0), None, 1, 2, None, True),          # all scales in one item
+    (3, (19, 40, 30), (1.0, 1.0, 1.0), [0, 4, 11, 19], 3, 1, 2, True),   # uneven cut, 3 line groups, scales 2 + 1
+    (4, (29, 24, 40), (0.8, 1.0, 1.25), None, 2, 2, 1, True),            # 8,7,7,7 planes, one scale per item
+    (4, (16, 20, 24), (1.0, 1.0, 1.0), None, 2, 2, 1, False),            # everything on the default group
 ])
 def test_slab_engine_equals_single_process_oracle(oracle, synth, tmp_path, world, shape, spacing,
-                                                  bounds, groups, steps, spi):
+                                                  bounds, groups, steps, spi, edge_groups):
     sigmas = [1.0, 2.0, 3.5]
-    got = _run_world(world, shape, sigmas, spacing, False, tmp_path, bounds, groups, steps, spi)
+    got = _run_world(world, shape, sigmas, spacing, False, tmp_path, bounds, groups, steps, spi,
+                     edge_groups)
     img, mask = _whole_volume(synth, shape)
     for s, sigma in enumerate(sigmas):
         ref = oracle.emphysema_features(img, mask, sigma, spacing)
