@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--iir-ckpt", type=int, default=None)
     ap.add_argument("--iir-fma", action="store_true", help="opt-in fused recurrences (not bit-exact)")
     ap.add_argument("--zchunk", type=int, default=None)
+    ap.add_argument("--no-fused-divide", action="store_true",
+                    help="IFE_OPT_FUSED_DIVIDE=0: two fields out of the last axis pass (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-slab", action="store_true",
                     help="run the Z-slab engine (RCCL exchanges) even with one rank")
@@ -295,6 +297,8 @@ class SingleGpuRunner:
             self.ctx.set_option(pkg.OPT_IIR_FMA, 1)
         if args.zchunk:
             self.ctx.set_option(pkg.OPT_ZCHUNK, args.zchunk)
+        if args.no_fused_divide:
+            self.ctx.set_option(pkg.OPT_FUSED_DIVIDE, 0)
         self.ctx.reserve(shape)
         self.config = {"input": "int16" if args.i16 else "float32", "spacing": list(self.spacing)}
 

@@ -26,6 +26,7 @@ F32, I16, U8, U16 = 0, 1, 2, 3
 INTERLEAVED, PLANAR = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 OPT_TRIG_MODE, OPT_DSCALE_MODE, OPT_PROFILE, OPT_ZCHUNK, OPT_IIR_BLOCK, OPT_IIR_CKPT, OPT_IIR_FMA = 1, 2, 3, 4, 5, 6, 7
+OPT_FUSED_DIVIDE = 8
 NUM_FEATURES = 8
 FEATURE_NAMES = ("GaussianBlur", "GradientMagnitude", "Eigenvalue1", "Eigenvalue2",
                  "Eigenvalue3", "LaplacianOfGaussian", "GaussianCurvature", "FrobeniusNorm")

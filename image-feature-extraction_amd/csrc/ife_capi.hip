@@ -84,6 +84,7 @@ struct ife_ctx {
   int iir_block = 0;   // 0: per axis (z 10 -- four waves per SIMD --, y 12, x 16); else 8 | 10 | 12 | 16
   int iir_fma = 0;   // 1: fused multiply-add in the line recurrences (opt-in, not bit-exact)
   int iir_ckpt = 2;  // register blocks per checkpoint of the strided line kernel: 1 or 2
+  int fused_divide = 1;  // last axis pass stores numerator / denominator (sibling waves), not two fields
   // per scale slot: numerator ping/pong, denominator ping/pong (up to three scales run
   // through the line kernels together)
   DevBuf fld[IFE_MAX_SLOTS][4];
@@ -393,9 +394,12 @@ int ensure_slots(ife_ctx *ctx, const ife_volume_desc *v, int nslots) {
 
 // One launch of the line kernel along `axis` over njobs independent float volumes
 // (jobs = numerator / denominator of up to three scales), each with its own sigma.
+// `in2` (strided axes, pair checkpoints only): jobs are PAIRED -- in[j] numerator, in2[j]
+// denominator, out[j] their quotient; job j uses checkpoint areas j and njobs + j.
 int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
                const float *const *in, float *const *out, const double *sigma,
-               int in_y_chunks = 1, const int *order = nullptr /* per job: 0 (default), 1, 2 */) {
+               int in_y_chunks = 1, const int *order = nullptr /* per job: 0 (default), 1, 2 */,
+               const float *const *in2 = nullptr) {
   if (njobs < 1 || njobs > IIR_MAX_JOBS) return fail(ctx, IFE_E_ARG, "bad job count %d", njobs);
   IirGeom g = geom_for_axis(v, axis);
   if (in_y_chunks > 1) {
@@ -410,7 +414,9 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
   if ((int64_t)2 * 16 * g.sstride * 4 >= (int64_t)1 << 31 ||
       g.outer * 4 >= (int64_t)1 << 32 || g.nlines * 8 * 3 >= (int64_t)1 << 32)
     return fail(ctx, IFE_E_SIZE, "volume too large for the 32-bit offsets of the line kernels");
-  int rc = ensure_ck(ctx, v, njobs);
+  if (in2 && (axis == 0 || 2 * njobs > IIR_MAX_JOBS || ctx->iir_ckpt != 2))
+    return fail(ctx, IFE_E_ARG, "the paired form runs on the strided axes with at most %d jobs", IIR_MAX_JOBS / 2);
+  int rc = ensure_ck(ctx, v, in2 ? 2 * njobs : njobs);
   if (rc) return rc;
   const double sp = axis == 0 ? v->sx : axis == 1 ? v->sy : v->sz;
   IirJobs jobs;
@@ -423,11 +429,17 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
     jobs.j[j].out = out[j];
     jobs.j[j].ck_y = (double *)ctx->ck_y[j].p;
     jobs.j[j].ck_x = (float *)ctx->ck_x[j].p;
+    if (in2) {
+      if (!in2[j] || in2[j] == out[j] || reinterpret_cast<uintptr_t>(in2[j]) % 4)
+        return fail(ctx, IFE_E_ARG, "bad denominator buffer");
+      jobs.j[j].in2 = in2[j];
+      jobs.j[j].ck_y2 = (double *)ctx->ck_y[njobs + j].p;
+    }
     if (gauss_coeffs_order(sigma[j], sp, order ? order[j] : 0, &jobs.j[j].c))
       return fail(ctx, IFE_E_ARG, "spacing is suspiciously small");
   }
   g.njobs = njobs;
-  g.ngroups = (int32_t)((g.nlines + 255) / 256);
+  g.ngroups = (int32_t)((g.nlines + (in2 ? 127 : 255)) / (in2 ? 128 : 256));  // paired: 128 lines x 2 fields
   const dim3 grid((unsigned)((g.ngroups + 7) / 8 * 8 * njobs), 1, 1);  // job-fastest, padded
   ProfScope ps(ctx, axis == 2 ? KK_IIR_Z : axis == 1 ? KK_IIR_Y : KK_IIR_X);
   // register block of the strided axes: z is bound by issue and gains from a fourth wave per
@@ -457,7 +469,22 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
         hipLaunchKernelGGL((NS::iir_strided_kernel<16>), grid, dim3(256), 0, ctx->stream, jobs, g); \
     }                                                                                           \
   } while (0)
-  if (ctx->iir_fma) IFE_LAUNCH_IIR(iir_fma);
+  if (in2) {
+#define IFE_LAUNCH_PAIRED(NS)                                                                          \
+  do {                                                                                                 \
+    if (sblock == 8)                                                                                   \
+      hipLaunchKernelGGL((NS::iir_strided_kernel<8, true>), grid, dim3(256), 0, ctx->stream, jobs, g);  \
+    else if (sblock == 10)                                                                             \
+      hipLaunchKernelGGL((NS::iir_strided_kernel<10, true>), grid, dim3(256), 0, ctx->stream, jobs, g); \
+    else if (sblock == 12)                                                                             \
+      hipLaunchKernelGGL((NS::iir_strided_kernel<12, true>), grid, dim3(256), 0, ctx->stream, jobs, g); \
+    else                                                                                               \
+      hipLaunchKernelGGL((NS::iir_strided_kernel<16, true>), grid, dim3(256), 0, ctx->stream, jobs, g); \
+  } while (0)
+    if (ctx->iir_fma) IFE_LAUNCH_PAIRED(iir_fma);
+    else IFE_LAUNCH_PAIRED(iir_exact);
+#undef IFE_LAUNCH_PAIRED
+  } else if (ctx->iir_fma) IFE_LAUNCH_IIR(iir_fma);
   else IFE_LAUNCH_IIR(iir_exact);
 #undef IFE_LAUNCH_IIR
   IFE_HIP(ctx, hipGetLastError());
@@ -595,9 +622,27 @@ int smooth_group(ife_ctx *ctx, const float *src_num, const float *src_den,
   rc = launch_iir(ctx, v, 2, nj, in, out, sg);
   fill(0, 1, false);                                   // X: ping -> pong
   if (!rc) rc = launch_iir(ctx, v, 0, nj, in, out, sg);
+  if (nf == 2 && ctx->fused_divide && ctx->iir_ckpt == 2) {
+    // Y: numerator and denominator in sibling waves, the quotient S goes to the numerator's slot
+    const float *n1[IIR_MAX_JOBS], *d1[IIR_MAX_JOBS];
+    float *o1[IIR_MAX_JOBS];
+    double s1[IIR_MAX_JOBS];
+    for (int k = 0; k < nscales; ++k) {
+      n1[k] = (const float *)ctx->fld[k][1].p;
+      d1[k] = (const float *)ctx->fld[k][3].p;
+      o1[k] = (float *)ctx->fld[k][0].p;
+      s1[k] = sigmas[k];
+    }
+    if (!rc) rc = launch_iir(ctx, v, 1, nscales, n1, o1, s1, 1, nullptr, d1);
+    return rc;
+  }
   fill(1, 0, false);                                   // Y: pong -> ping
   if (!rc) rc = launch_iir(ctx, v, 1, nj, in, out, sg);
   return rc;
+}
+// After smooth_group: is slot k's fld[k][0] already the quotient S (denominator folded in)?
+bool slots_hold_quotient(const ife_ctx *ctx, bool has_den) {
+  return has_den && ctx->fused_divide && ctx->iir_ckpt == 2;
 }
 
 template <int MODE, typename VAL, typename TM>
@@ -750,7 +795,8 @@ static int emphysema_typed(ife_ctx *ctx, const TI *img, const TM *msk, const ife
     for (int k = 0; k < ns; ++k) sg[k] = (double)sigmas[s0 + k];
     int rc = smooth_group(ctx, src_num, msk ? cf : nullptr, vol, sg, ns);
     for (int k = 0; k < ns && !rc; ++k) {
-      const ValSmooth vs{(const float *)ctx->fld[k][0].p, msk ? (const float *)ctx->fld[k][2].p : nullptr};
+      const bool q = slots_hold_quotient(ctx, msk != nullptr);
+      const ValSmooth vs{(const float *)ctx->fld[k][0].p, msk && !q ? (const float *)ctx->fld[k][2].p : nullptr};
       if (sink)
         rc = launch_features<FEAT_SAMPLES8>(ctx, vs, sink->code,
                                             sink->columns + (size_t)(s0 + k) * IFE_NUM_FEATURES * sink->stride,
@@ -855,6 +901,9 @@ int ife_ctx_set_option(ife_ctx *ctx, int option, int value) {
     case IFE_OPT_IIR_CKPT:
       if (value != 1 && value != 2) return fail(ctx, IFE_E_ARG, "iir checkpoint stride must be 1 or 2");
       ctx->iir_ckpt = value;
+      return IFE_OK;
+    case IFE_OPT_FUSED_DIVIDE:
+      ctx->fused_divide = value ? 1 : 0;
       return IFE_OK;
     case IFE_OPT_IIR_BLOCK:
       if (value != 0 && value != 8 && value != 10 && value != 12 && value != 16)
@@ -965,7 +1014,9 @@ int ife_normalized_gaussian_convolution(ife_ctx *ctx, const float *image,
   if (!rc) rc = smooth_group(ctx, tc, (const float *)dC, vol, &sg, 1);
   if (rc) return rc;
   const float *num = (const float *)ctx->fld[0][0].p, *den = (const float *)ctx->fld[0][2].p;
-  {
+  if (slots_hold_quotient(ctx, true)) {  // the last axis pass has divided already
+    IFE_HIP(ctx, hipMemcpyAsync(dO, num, n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  } else {
     ProfScope ps(ctx, KK_DIVIDE);
     hipLaunchKernelGGL(divide_kernel, dim3(2048), dim3(256), 0, ctx->stream, num, den,
                        (float *)dO, (int64_t)n);

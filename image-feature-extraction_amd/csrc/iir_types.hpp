@@ -53,6 +53,10 @@ struct IirJob {
   float *out;
   double *ck_y;  // [npairs][4][nlines]: y[i-1..i-4] at the start of every second block
   float *ck_x;   // [npairs][3][nlines]: x[i-1..i-3], contiguous-axis kernel only
+  // paired form (last pass of the normalized convolution): `in` is the numerator, `in2` the
+  // denominator with its own checkpoint area, `out` receives numerator / denominator
+  const float *in2;
+  double *ck_y2;
   IirCoef c;
 };
 struct IirJobs {

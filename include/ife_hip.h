@@ -87,7 +87,12 @@ typedef enum {
   /* 1: fuse each multiply-add of the recursive Gaussian (half the double operations).  Not
    * the reference's arithmetic: outputs differ by one float ulp at about one voxel in 10^8,
    * which the second differences can amplify past the 1e-5 bar there.  Default 0. */
-  IFE_OPT_IIR_FMA = 7
+  IFE_OPT_IIR_FMA = 7,
+  /* 1 (default): the last axis pass of the normalized convolution runs numerator and
+   * denominator in sibling waves and stores only their quotient (the Div functor,
+   * NormalizedGaussianConvolutionImageFilter.hxx:57-61); 0: two float fields and a division
+   * in the consumer.  Same results bit for bit. */
+  IFE_OPT_FUSED_DIVIDE = 8
 } ife_option;
 
 typedef struct {

@@ -273,6 +273,35 @@ def test_normalized_convolution_where_the_certainty_vanishes(ctx, oracle, synth)
     assert np.abs(ref[cert == 0]).max() < np.finfo(np.float32).max  # tiny denominators, finite quotients
 
 
+@pytest.mark.parametrize("block", [0, 8, 16])
+@pytest.mark.parametrize("shape", [(24, 28, 32), (9, 70, 66), (5, 4, 130), (6, 25, 200)])
+def test_fused_divide_option_is_invisible(ctx, ife, oracle, synth, shape, block):
+    """The last axis pass stores numerator / denominator (IFE_OPT_FUSED_DIVIDE=1, default:
+    sibling waves exchange through LDS) or two fields that the feature kernel divides (=0):
+    same bits, both equal to the oracle -- ragged line counts, partial blocks, fractional
+    certainties and the a4 entry point included."""
+    img = synth.volume_f32(shape, 21)
+    labels = synth.mask_ellipsoids(shape).astype(np.uint8)
+    labels[0, 0, :] = 2
+    ctx.set_option(ife.OPT_IIR_BLOCK, block)
+    try:
+        a = ctx.emphysema_features(img, labels, [1.0, 2.5])
+        cert = (labels > 0).astype(np.float32)
+        cert += np.float32(0.25) * (np.arange(cert.size).reshape(shape) % 3 == 0)
+        na = ctx.normalized_gaussian_convolution(img, cert, 0.9)
+        ctx.set_option(ife.OPT_FUSED_DIVIDE, 0)
+        b = ctx.emphysema_features(img, labels, [1.0, 2.5])
+        nb = ctx.normalized_gaussian_convolution(img, cert, 0.9)
+    finally:
+        ctx.set_option(ife.OPT_FUSED_DIVIDE, 1)
+        ctx.set_option(ife.OPT_IIR_BLOCK, 0)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(na, nb)
+    np.testing.assert_array_equal(na, oracle.normalized_gaussian_convolution(img, cert, 0.9))
+    for s, sigma in enumerate((1.0, 2.5)):
+        assert_features_close(a[s], oracle.emphysema_features(img, labels, sigma), labels)
+
+
 def test_emphysema_chunking_is_invisible(ctx, ife, synth):
     shape = (50, 20, 70)
     img = synth.volume_f32(shape, 12)
