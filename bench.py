@@ -39,7 +39,7 @@ KERNEL_ALG_BYTES = {"iir_z": 8.0, "iir_x": 8.0, "iir_y": 8.0, "features": 41.0, 
 # pass (profiles/r02_pmc_summary.txt: SQ_INSTS_VALU / waves' samples).  On CDNA4 a double
 # add / multiply occupies its SIMD for 4 cycles per wave, so
 #   issue_floor_ms = instructions x 4 / (256 CUs x 4 SIMDs x sustained clock).
-VALU_PER_WAVE64 = {"iir_z": 55.5, "iir_x": 56.2, "iir_y": 56.9, "features": 249.0}
+VALU_PER_WAVE64 = {"iir_z": 55.5, "iir_x": 56.2, "iir_y": 59.5, "features": 240.0}
 SIMDS, SUSTAINED_GHZ = 1024, 2.03  # GRBM_GUI_ACTIVE / 8 / duration under this load
 
 def parse():
@@ -255,7 +255,7 @@ def main():
                    "trig_mode": args.trig,
                    "trig_mode_meaning": {0: "double acos/cos (bit-faithful to the oracle)",
                                          1: "float overloads, correctly rounded",
-                                         2: "float polynomials, max error 3.6e-7 |lambda1| "
+                                         2: "float polynomials, max error 4.5e-7 |lambda1| over all of 512^3 x 3 scales "
                                             "(bar: 1e-5)"}.get(args.trig)},
         "volume_level_Mvoxels_per_s": round(nvox / t_step / 1e6, 1),
         "roofline": roofline,
