@@ -237,7 +237,7 @@ class SlabEngine:
                  scales_per_item=None):
         """alloc(shape, dtype_name) -> tensor ('float32' or 'uint8') on the compute device;
         bounds: W+1 plane indices (default: slab_bounds); line_groups: items per scale group on
-        the boundary chains (default 2 when world > 2, else 1); scales_per_item: scales whose
+        the boundary chains (default 4 up to four ranks, 2 beyond); scales_per_item: scales whose
         sweeps share a launch and a message (default: all of them up to four ranks -- the jobs of
         a launch share their input through L2 and the 64-plane launches of one scale leave most of
         the device idle: 512^3 on a 128-plane slab 3.13 ms per step against 3.61 -- else one, so
@@ -262,7 +262,10 @@ class SlabEngine:
         self.nf = nf = 2 if has_mask else 1
         S = len(self.sigmas)
         L = ny * nx
-        G = line_groups if line_groups is not None else (2 if world > 2 else 1)
+        # line groups pipeline a boundary: the transfer of one group travels while the next is
+        # swept.  Up to four ranks an item carries all scales (75 MB per boundary at 512^2 in one
+        # piece would expose 0.5 ms), so four groups; at eight, one scale per item, two
+        G = line_groups if line_groups is not None else (1 if world == 1 else 4 if world <= 4 else 2)
         G = max(1, min(G, (L + 255) // 256))
         per = ((L + G - 1) // G + 255) // 256 * 256  # whole workgroups of 256 lines
         self.groups = [(l0, min(L, l0 + per) - l0) for l0 in range(0, L, per)]
