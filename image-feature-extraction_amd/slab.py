@@ -233,7 +233,7 @@ class SlabEngine:
     """Runs all scales of the feature path on this rank's Z-slab."""
 
     def __init__(self, stages, comm, shape_zyx, spacing, sigmas, rank, world, alloc, layout,
-                 has_mask=True, overlap=True, line_groups=None, bounds=None, streams=None,
+                 has_mask=True, line_groups=None, bounds=None, streams=None,
                  scales_per_item=None):
         """alloc(shape, dtype_name) -> tensor ('float32' or 'uint8') on the compute device;
         bounds: W+1 plane indices (default: slab_bounds); line_groups: items per scale group on
@@ -258,7 +258,7 @@ class SlabEngine:
         self.z0, self.z1 = self.bounds[rank], self.bounds[rank + 1]
         self.nzl = nzl = self.z1 - self.z0
         self.spacing, self.sigmas, self.layout = tuple(spacing), list(sigmas), layout
-        self.has_mask, self.overlap = has_mask, overlap
+        self.has_mask = has_mask
         self.nf = nf = 2 if has_mask else 1
         S = len(self.sigmas)
         L = ny * nx
