@@ -43,6 +43,8 @@ EXPORTS = (
     "ife_get_kernel_times", "ife_reset_kernel_times",
     "ife_stage_prepare", "ife_stage_recursive_gaussian", "ife_stage_recursive_gaussian_batch",
     "ife_stage_features", "ife_stage_z_ck_bytes", "ife_stage_z_sweep", "ife_stage_z_combine",
+    "ife_multi_create", "ife_multi_destroy", "ife_multi_last_error", "ife_multi_set_option",
+    "ife_multi_emphysema_features",
     "ife_sort_f32", "ife_equalized_edges_f32", "ife_equalized_edges_f64", "ife_dense_histogram_f32", "ife_roi_histograms", "ife_bag_image",
     "ife_samples_create", "ife_samples_destroy", "ife_samples_count", "ife_samples_clear",
     "ife_samples_add_features", "ife_samples_add_image", "ife_samples_sort",
@@ -123,6 +125,13 @@ def load_library():
                                       C.POINTER(C.c_double), i32, vp, vp, C.POINTER(vp)]
     lib.ife_stage_z_combine.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), vd, i64, i64,
                                         C.POINTER(C.c_double), i32, i32, C.POINTER(vp)]
+    lib.ife_multi_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
+    lib.ife_multi_destroy.argtypes = [vp]
+    lib.ife_multi_destroy.restype = None
+    lib.ife_multi_last_error.argtypes = [vp]
+    lib.ife_multi_last_error.restype = C.c_char_p
+    lib.ife_multi_set_option.argtypes = [vp, i32, i32]
+    lib.ife_multi_emphysema_features.argtypes = [vp, vp, i32, vp, i32, vd, C.POINTER(C.c_float), i32, f32p, i32]
     lib.ife_get_kernel_times.argtypes = [vp, C.POINTER(KernelTime), i32]
     lib.ife_reset_kernel_times.argtypes = [vp]
     lib.ife_sort_f32.argtypes = [vp, vp, i64, vp, i32]
@@ -496,6 +505,54 @@ class Context:
 
     def samples(self, n_columns):
         return Samples(self, n_columns)
+
+
+class Multi:
+    """``ife_multi``: the Z-slab engine over several devices of one process (peer copies)."""
+
+    def __init__(self, devices):
+        self._lib = load_library()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = self._lib.ife_multi_create(devs, len(devices), C.byref(h))
+        if rc != OK:
+            raise IfeError(rc, self._lib.ife_multi_last_error(None).decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ife_multi_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise IfeError(rc, self._lib.ife_multi_last_error(self._h).decode())
+
+    def set_option(self, option, value):
+        self._chk(self._lib.ife_multi_set_option(self._h, int(option), int(value)))
+
+    def emphysema_features(self, image, mask, sigmas, spacing=(1.0, 1.0, 1.0), layout=INTERLEAVED):
+        image = np.ascontiguousarray(image)
+        if image.dtype not in _IMG_DT:
+            image = image.astype(np.float32)
+        mdt, mptr = U8, None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask)
+            mdt, mptr = _MSK_DT[mask.dtype], mask.ctypes.data
+        d = _desc(image.shape, spacing)
+        sig = (C.c_float * len(sigmas))(*[float(s) for s in sigmas])
+        shp = image.shape + (8,) if layout == INTERLEAVED else (8,) + image.shape
+        out = np.empty((len(sigmas),) + shp, np.float32)
+        self._chk(self._lib.ife_multi_emphysema_features(
+            self._h, image.ctypes.data, _IMG_DT[image.dtype], mptr, mdt, C.byref(d), sig,
+            len(sigmas), out.ctypes.data, layout))
+        return out
 
 
 class Samples:

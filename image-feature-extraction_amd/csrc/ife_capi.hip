@@ -1400,3 +1400,4 @@ int ife_reset_kernel_times(ife_ctx *ctx) {
 }  // extern "C"
 
 #include "stats_capi.inc"
+#include "multi_capi.inc"

@@ -60,6 +60,17 @@ class ImageToEmphysemaFeaturesFilter {
     out_->CopyInformation(image_);
     out_->SetNumberOfComponentsPerPixel(numFeatures);  // .hxx:83-90
     out_->Allocate();
+    if (ife_multi *multi = e.multi()) {  // IFE_DEVICES: Z-slabs over several devices
+      const float sig1 = (float)sigma_;
+      e.check_multi(ife_multi_emphysema_features(
+                        multi, image_->GetBufferPointer(), ife::host::ImageDType<PixelType>::value,
+                        mask_->GetBufferPointer(),
+                        ife::host::MaskDType<typename InputMaskType::PixelType>::value, &d, &sig1, 1,
+                        out_->GetBufferPointer(), IFE_INTERLEAVED),
+                    "ImageToEmphysemaFeaturesFilter");
+      dirty_ = false;
+      return;
+    }
     int which = -1;
     for (size_t k = 0; k < scales_.size(); ++k)
       if (scales_[k] == (float)sigma_) { which = (int)k; break; }

@@ -6,7 +6,9 @@
 #define IFE_HOST_ENGINE_H
 
 #include <cstdlib>
+#include <sstream>
 #include <string>
+#include <vector>
 
 #include "ife/Host/Image.h"
 #include "ife_hip.h"
@@ -34,13 +36,40 @@ class Engine {
   void check(int rc, const char *where) {
     if (rc != IFE_OK) throw itk::ExceptionObject(ife_last_error(ctx_), where);
   }
+  // IFE_DEVICES=0,1,2,3: the feature filter cuts the volume into Z-slabs over these devices
+  // (ife_multi_*, one host thread, peer copies).  Unset or one entry: nullptr.
+  ife_multi *multi() {
+    if (!multi_tried_) {
+      multi_tried_ = true;
+      std::vector<int> devs;
+      if (const char *d = std::getenv("IFE_DEVICES")) {
+        std::stringstream ss(d);
+        std::string tok;
+        while (std::getline(ss, tok, ','))
+          if (!tok.empty()) devs.push_back(std::atoi(tok.c_str()));
+      }
+      if (devs.size() > 1) {
+        if (ife_multi_create(devs.data(), (int)devs.size(), &multi_) != IFE_OK)
+          throw itk::ExceptionObject(ife_multi_last_error(nullptr), "ife::host::Engine");
+        if (const char *t = std::getenv("IFE_TRIG_MODE")) ife_multi_set_option(multi_, IFE_OPT_TRIG_MODE, std::atoi(t));
+        if (const char *t = std::getenv("IFE_DSCALE_MODE")) ife_multi_set_option(multi_, IFE_OPT_DSCALE_MODE, std::atoi(t));
+      }
+    }
+    return multi_;
+  }
+  void check_multi(int rc, const char *where) {
+    if (rc != IFE_OK) throw itk::ExceptionObject(ife_multi_last_error(multi_), where);
+  }
   ~Engine() {
+    if (multi_) ife_multi_destroy(multi_);
     if (ctx_) ife_ctx_destroy(ctx_);
   }
 
  private:
   Engine() = default;
   ife_ctx *ctx_ = nullptr;
+  ife_multi *multi_ = nullptr;
+  bool multi_tried_ = false;
 };
 
 inline ife_volume_desc describe(const itk::ImageBase3 &img) {

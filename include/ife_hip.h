@@ -291,6 +291,24 @@ int ife_stage_features(ife_ctx *ctx, const float *num, const float *den, const v
                        int mask_dtype, const ife_volume_desc *slab, int halo_lo, int halo_hi,
                        float *out, int layout);
 
+/* ---- several devices in one process --------------------------------------------------
+ *
+ * The same Z-slab decomposition driven from C++ by ONE host thread: device r of the list
+ * owns the r-th range of planes (nz / n planes each, remainder on the first ones; every
+ * slab needs 4), states and stencil planes travel by peer copies over xGMI, every dependency
+ * is a HIP event.  Host pointers in, host pointers out; blocks until the whole output is
+ * there.  Same results bit for bit as ife_emphysema_features on one device.  A device may be
+ * listed more than once (how a one-GPU box tests n > 1). */
+typedef struct ife_multi ife_multi;
+int ife_multi_create(const int *devices, int n_devices, ife_multi **out);
+void ife_multi_destroy(ife_multi *m);
+const char *ife_multi_last_error(const ife_multi *m);
+/* ife_ctx_set_option on every context of the engine */
+int ife_multi_set_option(ife_multi *m, int option, int value);
+int ife_multi_emphysema_features(ife_multi *m, const void *image, int image_dtype,
+                                 const void *mask, int mask_dtype, const ife_volume_desc *vol,
+                                 const float *sigmas, int n_sigmas, float *out, int layout);
+
 /* ---- rows f1 / f2: sample columns, equalizing histogram edges, dense histograms ------- *
  * The immediate consumer of the feature volume.  The samples never
  * leave HBM; only the nbins-1 edges per column come back.                                 */

@@ -161,6 +161,31 @@ def test_world_geometry_survives_the_tools(built, tmp_path, synth):
 
 
 @pytest.mark.gpu
+def test_extract_features_over_several_devices(built, tmp_path, synth):
+    """IFE_DEVICES: the tool cuts the volume into Z-slabs over the listed devices (the one GPU
+    of the test box named three times); files identical to the single-device run."""
+    shape = (24, 28, 32)
+    niftiio.write(str(tmp_path / "i.nii.gz"), synth.volume_f32(shape, 5), (0.9, 1.0, 1.1))
+    niftiio.write(str(tmp_path / "m.nii.gz"), np.minimum(synth.mask_ellipsoids(shape), 1).astype(np.uint8),
+                  (0.9, 1.0, 1.1))
+    outs = []
+    for devs in (None, "0,0,0"):
+        env = dict(os.environ)
+        env.pop("IFE_DEVICES", None)
+        if devs:
+            env["IFE_DEVICES"] = devs
+        base = str(tmp_path / ("o" + (devs or "single").replace(",", "")))
+        r = subprocess.run([os.path.join(BIN, "ExtractFeatures"), "-i", str(tmp_path / "i.nii.gz"), "-m",
+                            str(tmp_path / "m.nii.gz"), "-o", base, "-s", "1", "-s", "2.5"],
+                           capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        outs.append([niftiio.read(base + "_scale_%s%s.nii.gz" % (sc, f))[0]
+                     for sc in ("1.000000", "2.500000") for f in ("GaussianBlur", "Eigenvalue1", "FrobeniusNorm")])
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_host_selftest(built, tmp_path):
     r = subprocess.run([os.path.join(BIN, "host_selftest"), str(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
