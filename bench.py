@@ -62,6 +62,11 @@ def parse():
     ap.add_argument("--iir-ckpt", type=int, default=None)
     ap.add_argument("--iir-fma", action="store_true", help="opt-in fused recurrences (not bit-exact)")
     ap.add_argument("--zchunk", type=int, default=None)
+    ap.add_argument("--const-lines", type=int, default=0, choices=[0, 1],
+                    help="IFE_OPT_CONST_LINES.  The headline keeps it OFF: with the all-ones mask of "
+                         "this workload every denominator line is the constant 1 and would be copied "
+                         "instead of filtered; off, every voxel pays the full path.  (The library "
+                         "default is on; the time with it on is reported beside the headline.)")
     ap.add_argument("--no-fused-divide", action="store_true",
                     help="IFE_OPT_FUSED_DIVIDE=0: two fields out of the last axis pass (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -181,6 +186,18 @@ def main():
             ktimes[name] = (n0 + n, ms0 + ms)
         c.set_option(pkg.OPT_PROFILE, 0)
     copy_gbs = measured_copy_gbs(torch, dev) if rank == 0 else None
+    # beside the headline: the same step with the library's default constant-line shortcut
+    shortcut_ms = None
+    if not use_dist and not args.const_lines:
+        runner.ctx.set_option(pkg.OPT_CONST_LINES, 1)
+        runner.step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            runner.step()
+        torch.cuda.synchronize()
+        shortcut_ms = (time.perf_counter() - t1) / 3 * 1e3
+        runner.ctx.set_option(pkg.OPT_CONST_LINES, 0)
 
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -252,12 +269,16 @@ def main():
                                          % (world, runner.config.get("line_groups", 1)),
                                          "" if runner.config["spacing"] == [1.0, 1.0, 1.0]
                                          else ", spacing %s" % runner.config["spacing"]),
+                   "const_lines": args.const_lines,
+                   "const_lines_meaning": "0: every line is filtered (every voxel pays the full path); "
+                                          "1 (library default): lines that are all 0 or all 1 are copied",
                    "trig_mode": args.trig,
                    "trig_mode_meaning": {0: "double acos/cos (bit-faithful to the oracle)",
                                          1: "float overloads, correctly rounded",
                                          2: "float polynomials, max error 4.5e-7 |lambda1| over all of 512^3 x 3 scales "
                                             "(bar: 1e-5)"}.get(args.trig)},
         "volume_level_Mvoxels_per_s": round(nvox / t_step / 1e6, 1),
+        "ms_per_step_with_constant_line_shortcut": round(shortcut_ms, 3) if shortcut_ms else None,
         "roofline": roofline,
     }
     if rank == 0:
@@ -299,6 +320,7 @@ class SingleGpuRunner:
             self.ctx.set_option(pkg.OPT_ZCHUNK, args.zchunk)
         if args.no_fused_divide:
             self.ctx.set_option(pkg.OPT_FUSED_DIVIDE, 0)
+        self.ctx.set_option(pkg.OPT_CONST_LINES, args.const_lines)
         self.ctx.reserve(shape)
         self.config = {"input": "int16" if args.i16 else "float32", "spacing": list(self.spacing)}
 

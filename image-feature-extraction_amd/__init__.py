@@ -27,6 +27,7 @@ INTERLEAVED, PLANAR = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 OPT_TRIG_MODE, OPT_DSCALE_MODE, OPT_PROFILE, OPT_ZCHUNK, OPT_IIR_BLOCK, OPT_IIR_CKPT, OPT_IIR_FMA = 1, 2, 3, 4, 5, 6, 7
 OPT_FUSED_DIVIDE = 8
+OPT_CONST_LINES = 9
 NUM_FEATURES = 8
 FEATURE_NAMES = ("GaussianBlur", "GradientMagnitude", "Eigenvalue1", "Eigenvalue2",
                  "Eigenvalue3", "LaplacianOfGaussian", "GaussianCurvature", "FrobeniusNorm")

@@ -85,6 +85,7 @@ struct ife_ctx {
   int iir_fma = 0;   // 1: fused multiply-add in the line recurrences (opt-in, not bit-exact)
   int iir_ckpt = 2;  // register blocks per checkpoint of the strided line kernel: 1 or 2
   int fused_divide = 1;  // last axis pass stores numerator / denominator (sibling waves), not two fields
+  int const_lines = 1;   // lines that are all 0 (or all 1, where verified exact) are copied, not filtered
   // per scale slot: numerator ping/pong, denominator ping/pong (up to three scales run
   // through the line kernels together)
   DevBuf fld[IFE_MAX_SLOTS][4];
@@ -330,6 +331,40 @@ int gauss_coeffs_order(double sigma, double spacing, int order, IirCoef *c) {
   return 0;
 }
 
+// Does this filter map a line of n ones to exactly 1.0f at every sample?  The device runs the
+// same double operations in the same order (this translation unit is built with
+// -ffp-contract=off on both sides), so the answer found here holds there.  A constant 0 maps to
+// 0 with any coefficients.  (Restates FilterDataArray like iir_kernels.inc, for one line.)
+bool ones_stay_ones(const IirCoef &c, int64_t n) {
+  if (n < 4 || n > 65536) return false;
+  std::vector<double> ca((size_t)n);
+  double x1 = 1.0, x2 = 1.0, x3 = 1.0, y1 = 1.0, y2 = 1.0, y3 = 1.0, y4 = 1.0;
+  for (int64_t i = 0; i < n; ++i) {
+    const double d1 = i < 1 ? c.BN1 : c.D1, d2 = i < 2 ? c.BN2 : c.D2;
+    const double d3 = i < 3 ? c.BN3 : c.D3, d4 = i < 4 ? c.BN4 : c.D4;
+    const double a = x3 * c.N3 + (x2 * c.N2 + (x1 * c.N1 + 1.0 * c.N0));
+    const double t = y4 * d4 + (y3 * d3 + (y2 * d2 + y1 * d1));
+    const double y = a - t;
+    x3 = x2; x2 = x1; x1 = 1.0;
+    y4 = y3; y3 = y2; y2 = y1; y1 = y;
+    ca[(size_t)i] = y;
+  }
+  double u1 = 1.0, u2 = 1.0, u3 = 1.0, u4 = 1.0;
+  x1 = x2 = x3 = 1.0;
+  double x4 = 1.0;
+  for (int64_t i = n - 1; i >= 0; --i) {
+    const double d1 = i + 1 >= n ? c.BM1 : c.D1, d2 = i + 2 >= n ? c.BM2 : c.D2;
+    const double d3 = i + 3 >= n ? c.BM3 : c.D3, d4 = i + 4 >= n ? c.BM4 : c.D4;
+    const double a = x4 * c.M4 + (x3 * c.M3 + (x2 * c.M2 + x1 * c.M1));
+    const double t = u4 * d4 + (u3 * d3 + (u2 * d2 + u1 * d1));
+    const double y = a - t;
+    x4 = x3; x3 = x2; x2 = x1; x1 = 1.0;
+    u4 = u3; u3 = u2; u2 = u1; u1 = y;
+    if ((float)(ca[(size_t)i] + y) != 1.0f) return false;
+  }
+  return true;
+}
+
 // [ITK-upstream] DerivativeOperator coefficients after FlipAxes + ScaleCoefficients:
 // order 1 -> {-0.5, 0, 0.5} * s ; order 2 -> {1, -2, 1} * s  (s = 1/spacing, or
 // 1/spacing^2 for order 2 with IFE_OPT_DSCALE_MODE=1).
@@ -437,6 +472,20 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
     }
     if (gauss_coeffs_order(sigma[j], sp, order ? order[j] : 0, &jobs.j[j].c))
       return fail(ctx, IFE_E_ARG, "spacing is suspiciously small");
+    // constant lines are copied: zeros always (0 in, 0 out), ones where this filter keeps them
+    // (verified on the host for these coefficients and this line length; zero-order only)
+    jobs.j[j].const_lines = 0;
+    if (ctx->const_lines && !ctx->iir_fma && (!order || order[j] == 0)) {
+      const int64_t len = axis == 0 ? v->nx : axis == 1 ? v->ny : v->nz;
+      bool ok1 = false, seen = false;
+      for (int k = 0; k < j && !seen; ++k)  // the jobs of a launch mostly share their sigma
+        if (sigma[k] == sigma[j] && jobs.j[k].const_lines) {
+          seen = true;
+          ok1 = (jobs.j[k].const_lines & 2u) != 0;
+        }
+      if (!seen) ok1 = ones_stay_ones(jobs.j[j].c, len);
+      jobs.j[j].const_lines = 1u | (ok1 ? 2u : 0u);
+    }
   }
   g.njobs = njobs;
   g.ngroups = (int32_t)((g.nlines + (in2 ? 127 : 255)) / (in2 ? 128 : 256));  // paired: 128 lines x 2 fields
@@ -901,6 +950,9 @@ int ife_ctx_set_option(ife_ctx *ctx, int option, int value) {
     case IFE_OPT_IIR_CKPT:
       if (value != 1 && value != 2) return fail(ctx, IFE_E_ARG, "iir checkpoint stride must be 1 or 2");
       ctx->iir_ckpt = value;
+      return IFE_OK;
+    case IFE_OPT_CONST_LINES:
+      ctx->const_lines = value ? 1 : 0;
       return IFE_OK;
     case IFE_OPT_FUSED_DIVIDE:
       ctx->fused_divide = value ? 1 : 0;

@@ -57,6 +57,10 @@ struct IirJob {
   // denominator with its own checkpoint area, `out` receives numerator / denominator
   const float *in2;
   double *ck_y2;
+  // constant lines (a line whose samples are all 0, or all 1 where the host has verified that
+  // this filter maps the constant 1 to exactly 1.0f) are copied instead of filtered:
+  // bit 0 = allow 0, bit 1 = allow 1; 0 = always filter
+  uint32_t const_lines;
   IirCoef c;
 };
 struct IirJobs {

@@ -433,6 +433,7 @@ class SlabRunner:
                 c.set_option(pkg.OPT_IIR_FMA, 1)
             if getattr(args, "zchunk", None):
                 c.set_option(pkg.OPT_ZCHUNK, args.zchunk)
+            c.set_option(pkg.OPT_CONST_LINES, getattr(args, "const_lines", 0))
         dt = {"float32": torch.float32, "uint8": torch.uint8}
         alloc = lambda shp, d: torch.empty(shp, dtype=dt[d], device=dev)
         self.engine = SlabEngine(HipStages(pkg, self.ctx, self.chain_ctx),

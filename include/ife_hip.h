@@ -92,7 +92,12 @@ typedef enum {
    * denominator in sibling waves and stores only their quotient (the Div functor,
    * NormalizedGaussianConvolutionImageFilter.hxx:57-61); 0: two float fields and a division
    * in the consumer.  Same results bit for bit. */
-  IFE_OPT_FUSED_DIVIDE = 8
+  IFE_OPT_FUSED_DIVIDE = 8,
+  /* 1 (default): a line of the recursive Gaussian whose samples are all 0 -- or all 1, where
+   * the host has verified that this sigma and line length map the constant 1 to exactly 1.0f
+   * -- is copied instead of filtered (decided per wave of 64 adjacent lines): the exterior of
+   * a mask costs a read and a write.  Same results bit for bit; 0: every line is filtered. */
+  IFE_OPT_CONST_LINES = 9
 } ife_option;
 
 typedef struct {

@@ -46,9 +46,9 @@ def test_binding_enums_match_header(ife):
     assert (ife.F32, ife.I16, ife.U8, ife.U16) == tuple(
         val(n) for n in ("IFE_F32", "IFE_I16", "IFE_U8", "IFE_U16"))
     assert (ife.OPT_TRIG_MODE, ife.OPT_DSCALE_MODE, ife.OPT_PROFILE, ife.OPT_ZCHUNK,
-            ife.OPT_IIR_BLOCK, ife.OPT_IIR_CKPT, ife.OPT_IIR_FMA, ife.OPT_FUSED_DIVIDE) == tuple(val(n) for n in (
+            ife.OPT_IIR_BLOCK, ife.OPT_IIR_CKPT, ife.OPT_IIR_FMA, ife.OPT_FUSED_DIVIDE, ife.OPT_CONST_LINES) == tuple(val(n) for n in (
                 "IFE_OPT_TRIG_MODE", "IFE_OPT_DSCALE_MODE", "IFE_OPT_PROFILE", "IFE_OPT_ZCHUNK",
-                "IFE_OPT_IIR_BLOCK", "IFE_OPT_IIR_CKPT", "IFE_OPT_IIR_FMA", "IFE_OPT_FUSED_DIVIDE"))
+                "IFE_OPT_IIR_BLOCK", "IFE_OPT_IIR_CKPT", "IFE_OPT_IIR_FMA", "IFE_OPT_FUSED_DIVIDE", "IFE_OPT_CONST_LINES"))
     names = re.search(r"#define IFE_FEATURE_NAMES\s*\\\s*\{(.*?)\}", txt, re.S).group(1)
     assert tuple(re.findall(r'"(\w+)"', names)) == ife.FEATURE_NAMES
 

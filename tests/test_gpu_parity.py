@@ -302,6 +302,50 @@ def test_fused_divide_option_is_invisible(ctx, ife, oracle, synth, shape, block)
         assert_features_close(a[s], oracle.emphysema_features(img, labels, sigma), labels)
 
 
+@pytest.mark.parametrize("shape,kind", [((40, 70, 130), "exterior"), ((24, 28, 200), "ones"),
+                                        ((9, 140, 66), "slabs"), ((5, 4, 6), "tiny")])
+def test_constant_line_shortcut_is_invisible(ctx, ife, oracle, synth, shape, kind):
+    """IFE_OPT_CONST_LINES=1 (default) copies lines that are all 0 -- or all 1 where the host
+    found the filter to keep them -- instead of filtering them; =0 filters every line.  Same
+    bits, and both equal to the oracle: masks with a large exterior (whole waves of zero
+    lines along every axis), an all-ones mask (denominator lines of ones), masks made of
+    slabs (constant along one axis only), exact zeros inside the image."""
+    img = synth.volume_f32(shape, 33)
+    nz, ny, nx = shape
+    if kind == "exterior":
+        mask = np.zeros(shape, np.uint8)
+        mask[10:30, 20:50, 30:100] = 1
+    elif kind == "ones":
+        mask = np.ones(shape, np.uint8)
+        img[:, :, :70] = 0.0                      # numerator lines of zeros along x only in part
+        img[:, :10, :] = 0.0
+    elif kind == "slabs":
+        mask = np.zeros(shape, np.uint8)
+        mask[:, 64:, :] = 1                       # constant along z and x, a step along y
+        img[:, 70:, :] = 1.0                      # numerator lines of ones
+    else:
+        mask = np.ones(shape, np.uint8)
+    sig = [1.0, 3.0]
+    a = ctx.emphysema_features(img, mask, sig)
+    nc_a = ctx.normalized_gaussian_convolution(img, mask.astype(np.float32), 2.0)
+    ctx.set_option(ife.OPT_CONST_LINES, 0)
+    try:
+        b = ctx.emphysema_features(img, mask, sig)
+        nc_b = ctx.normalized_gaussian_convolution(img, mask.astype(np.float32), 2.0)
+    finally:
+        ctx.set_option(ife.OPT_CONST_LINES, 1)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(nc_a, nc_b)
+    np.testing.assert_array_equal(nc_a, oracle.normalized_gaussian_convolution(img, mask.astype(np.float32), 2.0))
+    for s, sigma in enumerate(sig):
+        ref = oracle.emphysema_features(img, mask, sigma)
+        # far inside a region of exact zeros the smoothed field decays to ~1e-24 and the
+        # reference's float p underflows: 0/0 in its solver, NaN in the same voxels here
+        nan = np.isnan(ref)
+        np.testing.assert_array_equal(np.isnan(a[s]), nan)
+        assert_features_close(np.where(nan, 0, a[s]), np.where(nan, 0, ref), mask)
+
+
 def test_emphysema_chunking_is_invisible(ctx, ife, synth):
     shape = (50, 20, 70)
     img = synth.volume_f32(shape, 12)
