@@ -807,6 +807,9 @@ int stage_out_end(ife_ctx *ctx, int mem, void *dst, size_t bytes) {
 int bind(ife_ctx *ctx) {
   if (!ctx) return IFE_E_ARG;
   IFE_HIP(ctx, hipSetDevice(ctx->device));
+  // hipGetLastError() after a launch must report THAT launch: drop whatever an earlier call of
+  // this thread (ours or another library's) left pending
+  (void)hipGetLastError();
   return IFE_OK;
 }
 
