@@ -67,6 +67,9 @@ def parse():
                          "this workload every denominator line is the constant 1 and would be copied "
                          "instead of filtered; off, every voxel pays the full path.  (The library "
                          "default is on; the time with it on is reported beside the headline.)")
+    ap.add_argument("--no-shortcut-leg", action="store_true",
+                    help="skip the four extra steps that time the constant-line shortcut beside the "
+                         "headline (the profiling scripts use it: every profiled launch is a headline launch)")
     ap.add_argument("--no-fused-divide", action="store_true",
                     help="IFE_OPT_FUSED_DIVIDE=0: two fields out of the last axis pass (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -188,7 +191,7 @@ def main():
     copy_gbs = measured_copy_gbs(torch, dev) if rank == 0 else None
     # beside the headline: the same step with the library's default constant-line shortcut
     shortcut_ms = None
-    if not use_dist and not args.const_lines:
+    if not use_dist and not args.const_lines and not args.no_shortcut_leg:
         runner.ctx.set_option(pkg.OPT_CONST_LINES, 1)
         runner.step()
         torch.cuda.synchronize()

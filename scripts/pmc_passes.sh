@@ -16,7 +16,7 @@ CGRP[fetch]="FETCH_SIZE"
 CGRP[write]="WRITE_SIZE GRBM_GUI_ACTIVE"
 for g in sq1 sq2 tcc1 fetch write; do
   rocprofv3 --kernel-trace --pmc ${CGRP[$g]} --output-format csv -d "$OUT/$g" -- \
-    python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$OUT/$g.json" 2> "$OUT/$g.err" \
+    python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-shortcut-leg "$@" > "$OUT/$g.json" 2> "$OUT/$g.err" \
     || { echo "pass $g failed"; tail -5 "$OUT/$g.err"; }
   echo "pass $g done"
 done
