@@ -39,7 +39,7 @@ KERNEL_ALG_BYTES = {"iir_z": 8.0, "iir_x": 8.0, "iir_y": 8.0, "features": 41.0, 
 # pass (profiles/r02_pmc_summary.txt: SQ_INSTS_VALU / waves' samples).  On CDNA4 a double
 # add / multiply occupies its SIMD for 4 cycles per wave, so
 #   issue_floor_ms = instructions x 4 / (256 CUs x 4 SIMDs x sustained clock).
-VALU_PER_WAVE64 = {"iir_z": 55.5, "iir_x": 56.2, "iir_y": 59.5, "features": 240.0}
+VALU_PER_WAVE64 = {"iir_z": 55.5, "iir_x": 57.2, "iir_y": 59.5, "features": 240.0}
 SIMDS, SUSTAINED_GHZ = 1024, 2.03  # GRBM_GUI_ACTIVE / 8 / duration under this load
 
 def parse():
