@@ -23,6 +23,15 @@ import time
 
 import numpy as np
 
+# N > 1: a rank drives nine streams (bulk, boundary chain, receive posting, and RCCL's own
+# stream per edge and traffic class).  HIP multiplexes streams onto GPU_MAX_HW_QUEUES
+# hardware queues (default 4), and a receive kernel that spins for its neighbour would hold
+# back whatever shares its queue; the slab engine's enqueue order keeps that free of deadlock
+# (slab.py), a queue per stream keeps it free of false waits too.  Read when the HIP runtime
+# starts, so it is set before anything touches the GPU; the caller's own value wins.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -133,7 +133,8 @@ class TorchComm:
     data through host memory (for backends that cannot take device tensors: gloo with the
     ranks of a test sharing one GPU)."""
 
-    def __init__(self, dist, rank, world, host_staging=False, per_edge_groups=True):
+    def __init__(self, dist, rank, world, host_staging=False, per_edge_groups=True, device=None):
+        """device: where the exchanged buffers live (a torch.device for RCCL; None = host)."""
         self.dist, self.rank, self.world, self.host = dist, rank, world, host_staging
         self.up, self.down, self.halo_g = [], [], []
         try:
@@ -151,6 +152,41 @@ class TorchComm:
             print("slab.TorchComm: per-edge communicators unavailable (%s); using the default group"
                   % exc, file=sys.stderr)
             self.up = self.down = self.halo_g = [None] * max(world - 1, 0)
+        self._handshake(device)
+
+    def _handshake(self, device):
+        """One tiny transfer per edge and traffic class, in an order no rank can block in:
+        even edges first, then odd ones, so the two ranks of an edge always meet.  RCCL builds a
+        communicator at its first use and that rendezvous blocks the host; left to the first
+        step, rank r would sit in its first send up (waiting for r+1 to receive) while r+1 sits
+        in its first send down (waiting for r).  Also leaves every communicator warm before
+        bench.py starts its clock."""
+        import torch
+        dist, r, W = self.dist, self.rank, self.world
+        dev = "cpu" if (self.host or device is None) else device
+        tok = lambda v: torch.full((4,), v, dtype=torch.uint8, device=dev)
+        for parity in (0, 1):
+            for e in (r - 1, r):
+                if e < 0 or e >= W - 1 or e % 2 != parity:
+                    continue
+                lower = r == e              # I am the lower rank of edge e
+                peer = e + 1 if lower else e
+                got_u, got_d, got_h = tok(0), tok(0), tok(0)
+                if lower:
+                    dist.isend(tok(1), peer, group=self.up[e]).wait()
+                    dist.irecv(got_d, peer, group=self.down[e]).wait()
+                else:
+                    dist.irecv(got_u, peer, group=self.up[e]).wait()
+                    dist.isend(tok(2), peer, group=self.down[e]).wait()
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, tok(3), peer, group=self.halo_g[e]),
+                                                 dist.P2POp(dist.irecv, got_h, peer, group=self.halo_g[e])]):
+                    w.wait()
+                if dev != "cpu":
+                    torch.cuda.synchronize(device)
+                want = [(got_d, 2), (got_h, 3)] if lower else [(got_u, 1), (got_h, 3)]
+                for t, v in want:
+                    if not bool((t == v).all()):
+                        raise RuntimeError("slab.TorchComm: handshake on edge %d returned wrong data" % e)
 
     def _isend(self, buf, dst, group):
         if self.host:
@@ -324,19 +360,15 @@ class SlabEngine:
                    self.src[1] if self.has_mask else None)
         prepared = rec(bulk)
 
-        # receives of the whole step, posted where nothing else is queued: each edge and class
-        # has its own communicator, and a buffer is only written again once the sweep that read
-        # it in the previous step has finished
-        recv = [[None] * n, [None] * n]
-        with on(post):
-            for i in range(n):
-                if has_lo:
-                    wait(post, self.consumed[0][i])
-                    recv[0][i] = comm.irecv_up(self.c_in[i])
-                if has_hi:
-                    wait(post, self.consumed[1][i])
-                    recv[1][i] = comm.irecv_down(self.a_in[i])
-
+        # A receive is ENQUEUED where its sweep stands in the schedule, never earlier: the
+        # schedule is a topological order of the whole job (every dependency has a smaller key
+        # on the neighbour), so even if the runtime ran all streams of a rank through one
+        # in-order hardware queue -- HIP shares a few queues among all streams -- a receive
+        # that spins for its sender can only hold back work that comes after it in that order.
+        # It is issued from the `post` stream, which holds nothing but event waits: the
+        # communicator's stream then waits for the sweep that read the buffer in the previous
+        # step and not for the sweeps queued on the chain stream, so the transfer of item i+1
+        # still travels under the sweep of item i.
         swept = [[None] * n, [None] * n]
         with on(chain):
             wait(chain, prepared)
@@ -348,7 +380,10 @@ class SlabEngine:
                 sin = (self.c_in if d == 0 else self.a_in)[i]
                 sout = (self.c_out if d == 0 else self.a_out)[i]
                 if has_nb:
-                    recv[d][i].wait()
+                    with on(post):
+                        wait(post, self.consumed[d][i])
+                        rx = comm.irecv_up(sin) if d == 0 else comm.irecv_down(sin)
+                    rx.wait()   # the chain stream (RCCL) or the host (gloo) waits for the state
                 if self.sent[d][i] is not None:  # last step's send still reads sout
                     self.sent[d][i].wait()
                     self.sent[d][i] = None
@@ -437,7 +472,7 @@ class SlabRunner:
         dt = {"float32": torch.float32, "uint8": torch.uint8}
         alloc = lambda shp, d: torch.empty(shp, dtype=dt[d], device=dev)
         self.engine = SlabEngine(HipStages(pkg, self.ctx, self.chain_ctx),
-                                 TorchComm(dist, rank, world), shape, spacing, sigmas, rank, world,
+                                 TorchComm(dist, rank, world, device=dev), shape, spacing, sigmas, rank, world,
                                  alloc, layout, has_mask=self.d_mask is not None,
                                  streams=self.streams,
                                  line_groups=getattr(args, "line_groups", None),
