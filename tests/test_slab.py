@@ -230,6 +230,7 @@ def _whole_volume(synth, shape):
     (3, (19, 40, 30), (1.0, 1.0, 1.0), [0, 4, 11, 19], 3, 1, 2, True),   # uneven cut, 3 line groups, scales 2 + 1
     (4, (29, 24, 40), (0.8, 1.0, 1.25), None, 2, 2, 1, True),            # 8,7,7,7 planes, one scale per item
     (4, (16, 20, 24), (1.0, 1.0, 1.0), None, 2, 2, 1, False),            # everything on the default group
+    (8, (37, 16, 40), (1.0, 1.0, 1.0), None, None, 2, None, True),       # eight ranks, the engine's own defaults there
 ])
 def test_slab_engine_equals_single_process_oracle(oracle, synth, tmp_path, world, shape, spacing,
                                                   bounds, groups, steps, spi, edge_groups):
