@@ -12,8 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
+#include <tuple>
 #include <type_traits>
 #include <vector>
 
@@ -85,7 +87,8 @@ struct ife_ctx {
   int iir_fma = 0;   // 1: fused multiply-add in the line recurrences (opt-in, not bit-exact)
   int iir_ckpt = 2;  // register blocks per checkpoint of the strided line kernel: 1 or 2
   int fused_divide = 1;  // last axis pass stores numerator / denominator (sibling waves), not two fields
-  int const_lines = 1;   // lines that are all 0 (or all 1, where verified exact) are copied, not filtered
+  int const_lines = 1;   // lines of one repeated 0 or 1 are copied, not filtered, where verified exact
+  std::map<std::tuple<double, double, int64_t>, uint32_t> const_flags;  // (sigma, spacing, length) -> IirJob::const_lines
   // per scale slot: numerator ping/pong, denominator ping/pong (up to three scales run
   // through the line kernels together)
   DevBuf fld[IFE_MAX_SLOTS][4];
@@ -331,38 +334,61 @@ int gauss_coeffs_order(double sigma, double spacing, int order, IirCoef *c) {
   return 0;
 }
 
-// Does this filter map a line of n ones to exactly 1.0f at every sample?  The device runs the
-// same double operations in the same order (this translation unit is built with
-// -ffp-contract=off on both sides), so the answer found here holds there.  A constant 0 maps to
-// 0 with any coefficients.  (Restates FilterDataArray like iir_kernels.inc, for one line.)
-bool ones_stay_ones(const IirCoef &c, int64_t n) {
+// Constant lines (IFE_OPT_CONST_LINES): what does the recursive Gaussian of this axis make of a
+// line whose n samples all have the value xin?  Simulated here in the arithmetic of the line
+// kernels -- the same double operations in the same order (this translation unit is built with
+// -ffp-contract=off on both sides), signs of zero included -- so the answer found here holds
+// there.  True when every output has the same bit pattern, returned in *resp.
+// (Restates FilterDataArray like iir_kernels.inc, for one line.)
+bool const_response(const IirCoef &c, int64_t n, double xin, float *resp) {
   if (n < 4 || n > 65536) return false;
   std::vector<double> ca((size_t)n);
-  double x1 = 1.0, x2 = 1.0, x3 = 1.0, y1 = 1.0, y2 = 1.0, y3 = 1.0, y4 = 1.0;
+  double x1 = xin, x2 = xin, x3 = xin, y1 = xin, y2 = xin, y3 = xin, y4 = xin;
   for (int64_t i = 0; i < n; ++i) {
     const double d1 = i < 1 ? c.BN1 : c.D1, d2 = i < 2 ? c.BN2 : c.D2;
     const double d3 = i < 3 ? c.BN3 : c.D3, d4 = i < 4 ? c.BN4 : c.D4;
-    const double a = x3 * c.N3 + (x2 * c.N2 + (x1 * c.N1 + 1.0 * c.N0));
+    const double a = x3 * c.N3 + (x2 * c.N2 + (x1 * c.N1 + xin * c.N0));
     const double t = y4 * d4 + (y3 * d3 + (y2 * d2 + y1 * d1));
     const double y = a - t;
-    x3 = x2; x2 = x1; x1 = 1.0;
+    x3 = x2; x2 = x1; x1 = xin;
     y4 = y3; y3 = y2; y2 = y1; y1 = y;
     ca[(size_t)i] = y;
   }
-  double u1 = 1.0, u2 = 1.0, u3 = 1.0, u4 = 1.0;
-  x1 = x2 = x3 = 1.0;
-  double x4 = 1.0;
+  double u1 = xin, u2 = xin, u3 = xin, u4 = xin;
+  x1 = x2 = x3 = xin;
+  double x4 = xin;
+  uint32_t first = 0;
   for (int64_t i = n - 1; i >= 0; --i) {
     const double d1 = i + 1 >= n ? c.BM1 : c.D1, d2 = i + 2 >= n ? c.BM2 : c.D2;
     const double d3 = i + 3 >= n ? c.BM3 : c.D3, d4 = i + 4 >= n ? c.BM4 : c.D4;
     const double a = x4 * c.M4 + (x3 * c.M3 + (x2 * c.M2 + x1 * c.M1));
     const double t = u4 * d4 + (u3 * d3 + (u2 * d2 + u1 * d1));
     const double y = a - t;
-    x4 = x3; x3 = x2; x2 = x1; x1 = 1.0;
+    x4 = x3; x3 = x2; x2 = x1; x1 = xin;
     u4 = u3; u3 = u2; u2 = u1; u1 = y;
-    if ((float)(ca[(size_t)i] + y) != 1.0f) return false;
+    const float o = (float)(ca[(size_t)i] + y);
+    uint32_t bits;
+    memcpy(&bits, &o, 4);
+    if (i == n - 1) first = bits;
+    else if (bits != first) return false;
   }
+  memcpy(resp, &first, 4);
   return true;
+}
+// IirJob::const_lines for one job: bit 0: a line of +0 comes out as +0; bit 1: a line of 1.0f as
+// 1.0f; bit 2 / bit 3: a line of -0 comes out as -0 / as +0 (T * 0 is -0 wherever T < 0, so the
+// exterior of a CT numerator is made of such lines).  Anything else is filtered.
+uint32_t const_line_flags(const IirCoef &c, int64_t n) {
+  uint32_t f = 0, bits;
+  float r;
+  if (const_response(c, n, 0.0, &r)) { memcpy(&bits, &r, 4); if (bits == 0u) f |= 1u; }
+  if (const_response(c, n, 1.0, &r) && r == 1.0f) f |= 2u;
+  if (const_response(c, n, -0.0, &r)) {
+    memcpy(&bits, &r, 4);
+    if (bits == 0x80000000u) f |= 4u;
+    else if (bits == 0u) f |= 8u;
+  }
+  return f;
 }
 
 // [ITK-upstream] DerivativeOperator coefficients after FlipAxes + ScaleCoefficients:
@@ -472,19 +498,19 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
     }
     if (gauss_coeffs_order(sigma[j], sp, order ? order[j] : 0, &jobs.j[j].c))
       return fail(ctx, IFE_E_ARG, "spacing is suspiciously small");
-    // constant lines are copied: zeros always (0 in, 0 out), ones where this filter keeps them
-    // (verified on the host for these coefficients and this line length; zero-order only)
+    // constant lines are copied where this filter provably maps the constant to a constant
+    // (const_line_flags: simulated on the host for these coefficients and this line length,
+    // remembered per context; zero-order only)
     jobs.j[j].const_lines = 0;
     if (ctx->const_lines && !ctx->iir_fma && (!order || order[j] == 0)) {
       const int64_t len = axis == 0 ? v->nx : axis == 1 ? v->ny : v->nz;
-      bool ok1 = false, seen = false;
-      for (int k = 0; k < j && !seen; ++k)  // the jobs of a launch mostly share their sigma
-        if (sigma[k] == sigma[j] && jobs.j[k].const_lines) {
-          seen = true;
-          ok1 = (jobs.j[k].const_lines & 2u) != 0;
-        }
-      if (!seen) ok1 = ones_stay_ones(jobs.j[j].c, len);
-      jobs.j[j].const_lines = 1u | (ok1 ? 2u : 0u);
+      const std::tuple<double, double, int64_t> key(sigma[j], sp, len);
+      auto it = ctx->const_flags.find(key);
+      if (it == ctx->const_flags.end()) {
+        if (ctx->const_flags.size() > 256) ctx->const_flags.clear();
+        it = ctx->const_flags.emplace(key, const_line_flags(jobs.j[j].c, len)).first;
+      }
+      jobs.j[j].const_lines = it->second;
     }
   }
   g.njobs = njobs;

@@ -93,10 +93,12 @@ typedef enum {
    * NormalizedGaussianConvolutionImageFilter.hxx:57-61); 0: two float fields and a division
    * in the consumer.  Same results bit for bit. */
   IFE_OPT_FUSED_DIVIDE = 8,
-  /* 1 (default): a line of the recursive Gaussian whose samples are all 0 -- or all 1, where
-   * the host has verified that this sigma and line length map the constant 1 to exactly 1.0f
-   * -- is copied instead of filtered (decided per wave of 64 adjacent lines): the exterior of
-   * a mask costs a read and a write.  Same results bit for bit; 0: every line is filtered. */
+  /* 1 (default): a line of the recursive Gaussian whose samples all have one bit pattern --
+   * +0, -0 (T * 0 where T < 0) or 1.0f -- is answered with the constant the filter makes of
+   * it, where the host has established that constant by running this sigma and line length
+   * through the kernels' arithmetic (decided per wave of 64 adjacent lines): the exterior of a
+   * mask costs a read and a write.  Same results bit for bit, signs of zero included; 0:
+   * every line is filtered. */
   IFE_OPT_CONST_LINES = 9
 } ife_option;
 

@@ -346,6 +346,46 @@ def test_constant_line_shortcut_is_invisible(ctx, ife, oracle, synth, shape, kin
         assert_features_close(np.where(nan, 0, a[s]), np.where(nan, 0, ref), mask)
 
 
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_constant_line_shortcut_keeps_the_sign_of_zero(ctx, ife, oracle, axis):
+    """Lines of +0, of -0 (T * 0 where T < 0: the exterior of a CT numerator), of mixed zeros,
+    of ones and of another constant, on every axis: with the shortcut on, the output has the
+    bit patterns -- signs of zero included -- of the filtered line (shortcut off, and the
+    oracle)."""
+    import torch
+    shape = (70, 130, 72)                                   # z, y, x: partial waves on every axis
+    rng = np.random.default_rng(5)
+    vol = rng.standard_normal(shape).astype(np.float32)
+    mv = np.moveaxis(vol, 2 - axis, 0)                      # lines of this axis first: [n][a][b]
+    na, nb = mv.shape[1], mv.shape[2]
+    kind = (np.arange(na)[:, None] // 3 + np.arange(nb)[None, :] // 70) % 7
+    mv[:, kind == 0] = 0.0
+    mv[:, kind == 1] = -0.0
+    mv[:, kind == 2] = 1.0
+    mv[:, kind == 3] = 2.5
+    alt = np.where(np.arange(mv.shape[0]) % 2 == 0, 0.0, -0.0).astype(np.float32)
+    mv[:, kind == 4] = alt[:, None]                         # zeros of both signs along the line
+    assert np.signbit(vol).any() and (vol == 0).any()
+    d_in = torch.from_numpy(np.ascontiguousarray(vol)).cuda()
+    res = {}
+    for opt in (1, 0):
+        ctx.set_option(ife.OPT_CONST_LINES, opt)
+        try:
+            for sigma in (1.0, 2.7):
+                d_out = torch.full(shape, 7.0, dtype=torch.float32, device="cuda")
+                ctx.stage_recursive_gaussian(d_in.data_ptr(), d_out.data_ptr(), shape, (1.0, 1.0, 1.0),
+                                             axis, sigma)
+                ctx.synchronize()
+                res[opt, sigma] = d_out.cpu().numpy()
+        finally:
+            ctx.set_option(ife.OPT_CONST_LINES, 1)
+    for sigma in (1.0, 2.7):
+        ref = oracle.recursive_gaussian_axis(vol, axis, sigma)
+        for opt in (1, 0):
+            np.testing.assert_array_equal(res[opt, sigma].view(np.uint32), ref.view(np.uint32),
+                                          err_msg="axis %d sigma %g const_lines %d" % (axis, sigma, opt))
+
+
 def test_emphysema_chunking_is_invisible(ctx, ife, synth):
     shape = (50, 20, 70)
     img = synth.volume_f32(shape, 12)
