@@ -151,10 +151,13 @@ constexpr int FT_NLD = (FT_NE + FT_THREADS - 1) / FT_THREADS;  // staged element
 //  * a second difference float((a - 2c) + b) takes one fma (2c is exact) and one add.
 // Both forms are bit-identical to the generic inner products, except that the sign of
 // an exact zero is not tracked (+0/-0 compare equal and never reach a non-zero output).
-// output stores of the feature kernel: 0 plain, 1 non-temporal (measured: no difference,
-// 1.540 vs 1.533 ms; kept as a switch)
+// output stores of the feature kernel: 0 plain, 1 non-temporal.  Round 1 (1.54 ms kernel):
+// no difference.  Round 2, with the kernel at 1.25 ms and bound by its stores: 1.274 -> 1.237
+// ms per launch and the prepass that follows the last launch 0.349 -> 0.317 (it no longer
+// shares the memory system with 4 GB of dirty lines being written back): step 10.17 -> 10.00
+// on one box, twice.  Nothing reads the outputs again inside the call.
 #ifndef IFE_FT_NT
-#define IFE_FT_NT 0
+#define IFE_FT_NT 1
 #endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -523,6 +526,20 @@ __device__ __forceinline__ int64_t prep_out_index(const PrepGeom &g, int64_t i) 
   const int64_t h = y / g.nyl, yy = y % g.nyl;
   return ((h * g.nz + z) * g.nyl + yy) * g.nx + x;
 }
+// cache policy of the prepass (experiments README): its outputs are read by the Z pass next,
+// its inputs by nobody before the next call
+#ifndef IFE_PREP_ST_NT
+#define IFE_PREP_ST_NT 0
+#endif
+#ifndef IFE_PREP_LD_NT
+#define IFE_PREP_LD_NT 0
+#endif
+#if IFE_PREP_ST_NT
+#define IFE_PREP_STORE(ptr, v) \
+  __builtin_nontemporal_store(f32x4{(v).x, (v).y, (v).z, (v).w}, reinterpret_cast<f32x4 *>(ptr))
+#else
+#define IFE_PREP_STORE(ptr, v) (*(ptr) = (v))
+#endif
 template <typename TI, typename TM>
 __global__ __launch_bounds__(256) void prep_kernel_vec4(const TI *__restrict__ img,
                                                         const TM *__restrict__ msk,
@@ -534,16 +551,20 @@ __global__ __launch_bounds__(256) void prep_kernel_vec4(const TI *__restrict__ i
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n4; i += stride) {
+#if IFE_PREP_LD_NT
+    const TI4 a = __builtin_nontemporal_load(reinterpret_cast<const TI4 *>(img) + i);
+#else
     const TI4 a = reinterpret_cast<const TI4 *>(img)[i];
+#endif
     float4 t = make_float4((float)a.x, (float)a.y, (float)a.z, (float)a.w);
     const int64_t o = prep_out_index(g, 4 * i) / 4;  // nx % 4 == 0 on this path
     if (msk != nullptr) {
       const TM4 m = reinterpret_cast<const TM4 *>(msk)[i];
       const float4 c = make_float4((float)m.x, (float)m.y, (float)m.z, (float)m.w);
       t.x *= c.x; t.y *= c.y; t.z *= c.z; t.w *= c.w;
-      if (cf != nullptr) reinterpret_cast<float4 *>(cf)[o] = c;
+      if (cf != nullptr) IFE_PREP_STORE(reinterpret_cast<float4 *>(cf) + o, c);
     }
-    reinterpret_cast<float4 *>(tc)[o] = t;
+    IFE_PREP_STORE(reinterpret_cast<float4 *>(tc) + o, t);
   }
 }
 template <typename TI, typename TM>
