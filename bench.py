@@ -157,7 +157,11 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # a transfer that has not completed after three minutes is a deadlock, not a slow link:
+        # the watchdog then ends the job instead of leaving kernels spinning on the GPUs
+        import datetime
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                timeout=datetime.timedelta(seconds=180))
 
     pkg = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synthetic")
