@@ -57,9 +57,9 @@ struct IirJob {
   // denominator with its own checkpoint area, `out` receives numerator / denominator
   const float *in2;
   double *ck_y2;
-  // constant lines (a line whose samples are all 0, or all 1 where the host has verified that
-  // this filter maps the constant 1 to exactly 1.0f) are copied instead of filtered:
-  // bit 0 = allow 0, bit 1 = allow 1; 0 = always filter
+  // constant lines (IFE_OPT_CONST_LINES): a line made of one bit pattern is answered with the
+  // constant the host found this filter to make of it (ife_capi.hip const_line_flags): bit 0:
+  // +0 -> +0, bit 1: 1.0f -> 1.0f, bit 2: -0 -> -0, bit 3: -0 -> +0; 0 = always filter
   uint32_t const_lines;
   IirCoef c;
 };
