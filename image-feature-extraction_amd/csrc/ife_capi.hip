@@ -571,7 +571,7 @@ constexpr int ZSLAB_K = 12;  // register block of the slab kernels (fixes the ch
 int64_t zslab_pairs(int64_t n) { return ((n + ZSLAB_K - 1) / ZSLAB_K + 1) / 2; }
 size_t zslab_ck_bytes(const ife_volume_desc *v) {
   const size_t L = (size_t)(v->nx * v->ny);
-  return (size_t)zslab_pairs(v->nz) * 4 * L * 2 * sizeof(double) + 2 * 4 * L * sizeof(float);
+  return (size_t)zslab_pairs(v->nz) * 4 * L * 2 * sizeof(double);
 }
 // phase 0: causal sweep, 1: anticausal sweep, 2: combine
 int launch_zslab(ife_ctx *ctx, int phase, int njobs, const float *const *in, float *const *out,
@@ -604,20 +604,10 @@ int launch_zslab(ife_ctx *ctx, int phase, int njobs, const float *const *in, flo
     J.out = phase == 2 ? out[j] + line0 : nullptr;
     double *cy = (double *)ck[j];
     double *ay = cy + np * 4 * L;
-    float *cx = (float *)(ay + np * 4 * L);
-    float *ax = cx + 4 * L;
-    J.cy = cy + line0; J.ay = ay + line0; J.cx = cx + line0; J.ax = ax + line0;
-    const size_t rec = (size_t)nlines * 48;  // [4][nlines] doubles, then [4][nlines] floats
-    if (state_in) {
-      const char *b = (const char *)state_in + (size_t)j * rec;
-      J.sin_y = (const double *)b;
-      J.sin_x = (const float *)(b + (size_t)nlines * 32);
-    }
-    if (state_out) {
-      char *b = (char *)state_out + (size_t)j * rec;
-      J.sout_y = (double *)b;
-      J.sout_x = (float *)(b + (size_t)nlines * 32);
-    }
+    J.cy = cy + line0; J.ay = ay + line0;
+    const size_t rec = (size_t)nlines * IFE_Z_STATE_BYTES;  // [4][nlines] doubles per job
+    if (state_in) J.sin_y = (const double *)((const char *)state_in + (size_t)j * rec);
+    if (state_out) J.sout_y = (double *)((char *)state_out + (size_t)j * rec);
     if (!(sigmas[j] > 0.0) || gauss_coeffs(sigmas[j], v->sz, &J.c))
       return fail(ctx, IFE_E_ARG, "bad sigma or spacing");
   }

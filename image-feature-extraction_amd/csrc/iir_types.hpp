@@ -69,22 +69,23 @@ struct IirJobs {
 
 // ---- Z pass of a Z-slab (multi-GPU): the recursion state crosses the slab boundary -------
 // A slab holds planes [z0, z1) of every Z line.  The causal recursion enters from the slab
-// below with the state (y[z0-1..z0-4], x[z0-1..z0-3]) and leaves with the same record at
-// z1; the anticausal one enters from above with (y[z1..z1+3], x[z1..z1+3]) and leaves
-// with the record at z0.  A record is 4 doubles + 4 floats per line, struct-of-arrays:
-// y[k][line] (k = 0: nearest sample), then x[k][line].  Every pair of register blocks has
-// one causal checkpoint (the y values in front of its first sample) and one anticausal
-// checkpoint (the y values in front of its last sample, coming from above); the x history
-// of a checkpoint is re-read from the samples around the pair, that of the slab's incoming
-// states is kept once.  The combine kernel rebuilds both recursions of a pair from them --
-// the same sequential arithmetic as the single-device kernel, sample for sample.
+// below with the state y[z0-1..z0-4] and leaves with y[z1-1..z1-4]; the anticausal one enters
+// from above with y[z1..z1+3] and leaves with y[z0..z0+3].  A record is those 4 doubles per
+// line, struct-of-arrays y[k][line] (k = 0: nearest sample): 32 B per line and job.  The x
+// history that belongs to a state (x[z0-1..z0-3], x[z1..z1+3]) does not travel: the INPUT of
+// a slab with a neighbour carries that neighbour's adjacent planes (3 below `in`, 4 above
+// its last plane), which every rank can produce from its own copy of the raw data.  Every
+// pair of register blocks has one causal checkpoint (the y values in front of its first
+// sample) and one anticausal checkpoint (the y values in front of its last sample, coming
+// from above); their x history too is re-read from the samples around the pair.  The combine
+// kernel rebuilds both recursions of a pair from them -- the same sequential arithmetic as the
+// single-device kernel, sample for sample.
 struct ZSlabJob {
-  const float *in;
+  const float *in;         // plane 0 of the slab; planes -3..-1 / n..n+3 readable where a neighbour exists
   float *out;              // combine only
-  double *cy, *ay;  // causal / anticausal checkpoints: the four y values, [npairs][4][ck_stride]
-  float *cx, *ax;   // x history of the incoming causal / anticausal state, [4][ck_stride]
-  const double *sin_y; const float *sin_x;  // incoming state of the sweep, [4][nlines]
-  double *sout_y; float *sout_x;            // outgoing state of the sweep, [4][nlines]
+  double *cy, *ay;         // causal / anticausal checkpoints: the four y values, [npairs][4][ck_stride]
+  const double *sin_y;     // incoming state of the sweep, [4][nlines]
+  double *sout_y;          // outgoing state of the sweep, [4][nlines]
   IirCoef c;
 };
 struct ZSlabJobs {

@@ -12,9 +12,12 @@ Everything is slab-local except two things:
     line.  It is kept exactly sequential by handing the recursion STATE across the slab
     boundaries (C-ABI `ife_stage_z_sweep` / `ife_stage_z_combine`): the causal chain
     travels rank 0 -> W-1, the anticausal chain W-1 -> 0, both at once, as records of
-    4 doubles + 4 floats per line and (scale, field); each rank then rebuilds both
-    recursions of its slab from checkpoints.  Stitched, this is bit for bit the
-    single-device result.
+    4 doubles per line and (scale, field): the last four outputs of the recursion.  The
+    input samples such a state refers to do not travel: a rank's slab of the RAW data is
+    cut with an overlap of 3 planes below and 4 above (`overlap(rank, world)`), which every
+    rank can take from wherever its data comes from, and the prepass runs over the
+    overlap too.  Each rank then rebuilds both recursions of its slab from checkpoints.
+    Stitched, this is bit for bit the single-device result.
   * the +-1 plane stencil of the feature kernel: one boundary plane of numerator and
     denominator per scale to each Z neighbour.
 
@@ -27,8 +30,8 @@ Per step and rank (S scales, nf = 2 fields with a mask, G line groups per scale)
   bulk stream, per scale group (all scales up to four ranks, else one scale):
       combine (Z output), X pass, Y pass, halo exchange, features               (local)
 
-Bytes over xGMI per boundary, direction and step: 48 B x nx*ny x S x nf (512^2, 3 scales,
-2 fields: 75 MB) + one plane of 2 fields per scale (6 MB); neighbours only.
+Bytes over xGMI per boundary, direction and step: 32 B x nx*ny x S x nf (512^2, 3 scales,
+2 fields: 50 MB) + one plane of 2 fields per scale (6 MB); neighbours only.
 
 The order of the sweeps on a rank is static: sorted by the hop count after which the state
 can arrive (causal item i at rank r: r + i; anticausal: W-1-r + i; ties causal first).
@@ -43,7 +46,13 @@ import contextlib
 
 import numpy as np
 
-STATE_BYTES_PER_LINE = 48  # 4 doubles + 4 floats (include/ife_hip.h, ife_stage_z_sweep)
+STATE_BYTES_PER_LINE = 32      # 4 doubles (include/ife_hip.h: IFE_Z_STATE_BYTES)
+OVERLAP_LO, OVERLAP_HI = 3, 4  # neighbour planes in front of / behind a slab's input (IFE_Z_OVERLAP_*)
+
+
+def overlap(rank, world):
+    """(planes below, planes above) that rank's slab of the raw data carries beyond its own."""
+    return (OVERLAP_LO if rank > 0 else 0, OVERLAP_HI if rank < world - 1 else 0)
 
 
 def slab_bounds(nz, world):
@@ -83,16 +92,19 @@ class HipStages:
                                mdt, tuple(img.shape), tc.data_ptr(),
                                cf.data_ptr() if cf is not None else None, 1)
 
-    def z_sweep(self, direction, srcs, spacing, sigmas, line0, nlines, has_neighbour, state_in,
-                state_out, cks):
-        self.chain_ctx.stage_z_sweep(direction, [t.data_ptr() for t in srcs], tuple(srcs[0].shape),
+    def z_sweep(self, direction, srcs_ext, pad_lo, nzl, spacing, sigmas, line0, nlines, has_neighbour,
+                state_in, state_out, cks):
+        """srcs_ext: the fields WITH their overlap planes; the slab's own planes start at pad_lo."""
+        own = [t[pad_lo:pad_lo + nzl] for t in srcs_ext]  # data_ptr() of a view is its first plane
+        self.chain_ctx.stage_z_sweep(direction, [t.data_ptr() for t in own], tuple(own[0].shape),
                                      spacing, line0, nlines, sigmas, has_neighbour,
                                      state_in.data_ptr() if has_neighbour else None,
                                      state_out.data_ptr(), [c.data_ptr() for c in cks])
 
-    def z_combine(self, srcs, dsts, spacing, sigmas, has_lo, has_hi, cks):
-        shape = tuple(srcs[0].shape)
-        self.ctx.stage_z_combine([t.data_ptr() for t in srcs], [t.data_ptr() for t in dsts], shape,
+    def z_combine(self, srcs_ext, pad_lo, nzl, dsts, spacing, sigmas, has_lo, has_hi, cks):
+        own = [t[pad_lo:pad_lo + nzl] for t in srcs_ext]
+        shape = tuple(own[0].shape)
+        self.ctx.stage_z_combine([t.data_ptr() for t in own], [t.data_ptr() for t in dsts], shape,
                                  spacing, 0, shape[1] * shape[2], sigmas, has_lo, has_hi,
                                  [c.data_ptr() for c in cks])
 
@@ -273,7 +285,7 @@ class SlabEngine:
                  scales_per_item=None):
         """alloc(shape, dtype_name) -> tensor ('float32' or 'uint8') on the compute device;
         bounds: W+1 plane indices (default: slab_bounds); line_groups: items per scale group on
-        the boundary chains (default 4 up to four ranks, 2 beyond); scales_per_item: scales whose
+        the boundary chains (default 4 up to four ranks, 3 beyond); scales_per_item: scales whose
         sweeps share a launch and a message (default: all of them up to four ranks -- the jobs of
         a launch share their input through L2 and the 64-plane launches of one scale leave most of
         the device idle: 512^3 on a 128-plane slab 3.13 ms per step against 3.61 -- else one, so
@@ -299,9 +311,12 @@ class SlabEngine:
         S = len(self.sigmas)
         L = ny * nx
         # line groups pipeline a boundary: the transfer of one group travels while the next is
-        # swept.  Up to four ranks an item carries all scales (75 MB per boundary at 512^2 in one
-        # piece would expose 0.5 ms), so four groups; at eight, one scale per item, two
-        G = line_groups if line_groups is not None else (1 if world == 1 else 4 if world <= 4 else 2)
+        # swept, and a chain's start-up (W-1 hops of sweep + wire + latency) shrinks with the item.
+        # Up to four ranks an item carries all scales, four groups.  At eight, one scale per item
+        # and three groups: 5.6 MB per item at 512^2 -- at the 60-75 GB/s a direction of an xGMI
+        # link carries, 7 hops of (16 + 80 + 30) us; two groups would start 0.4 ms later, four cost
+        # a third more point-to-point calls per step on a host thread that must stay ahead
+        G = line_groups if line_groups is not None else (1 if world == 1 else 4 if world <= 4 else 3)
         G = max(1, min(G, (L + 255) // 256))
         per = ((L + G - 1) // G + 255) // 256 * 256  # whole workgroups of 256 lines
         self.groups = [(l0, min(L, l0 + per) - l0) for l0 in range(0, L, per)]
@@ -324,7 +339,8 @@ class SlabEngine:
                 self.bulk_groups.append([q])
         self.schedule = sweep_schedule(rank, world, len(self.items))
         f = lambda *shp: alloc(shp, "float32")
-        self.src = [f(nzl, ny, nx) for _ in range(nf)]                      # tc, cf
+        self.pad_lo, self.pad_hi = overlap(rank, world)
+        self.src = [f(self.pad_lo + nzl + self.pad_hi, ny, nx) for _ in range(nf)]  # tc, cf with overlap
         self.zo = [[f(nzl, ny, nx) for _ in range(nf)] for _ in range(S)]   # Z-pass output
         self.xo = [[f(nzl, ny, nx) for _ in range(nf)] for _ in range(S)]   # X-pass output
         self.pad = [[f(nzl + 2, ny, nx) for _ in range(nf)] for _ in range(S)]  # Y output + halo planes
@@ -342,8 +358,12 @@ class SlabEngine:
 
     # ---- one step -------------------------------------------------------------------
     def run(self, img_slab, mask_slab, out):
-        """img_slab [nzl][ny][nx] f32|i16, mask_slab same shape u8|u16 or None,
-        out [S][nzl][ny][nx][8] (or [S][8][nzl][ny][nx] planar) float32."""
+        """img_slab [pad_lo + nzl + pad_hi][ny][nx] f32|i16: the rank's planes of the raw volume
+        with the overlap of `overlap(rank, world)`; mask_slab the same planes, u8|u16, or None;
+        out [S][nzl][ny][nx][8] (or [S][8][nzl][ny][nx] planar) float32: the rank's own planes."""
+        if img_slab.shape[0] != self.pad_lo + self.nzl + self.pad_hi:
+            raise ValueError("the slab of rank %d needs %d + %d + %d planes (overlap below, own, above), got %d"
+                             % (self.rank, self.pad_lo, self.nzl, self.pad_hi, img_slab.shape[0]))
         st, comm, sy = self.st, self.comm, self.sync
         nf, sp, W, r = self.nf, self.spacing, self.W, self.rank
         has_lo, has_hi = r > 0, r < W - 1
@@ -387,7 +407,7 @@ class SlabEngine:
                 if self.sent[d][i] is not None:  # last step's send still reads sout
                     self.sent[d][i].wait()
                     self.sent[d][i] = None
-                st.z_sweep(d, [self.src[k] for _ in ss for k in range(nf)], sp,
+                st.z_sweep(d, [self.src[k] for _ in ss for k in range(nf)], self.pad_lo, self.nzl, sp,
                            [self.sigmas[s] for s in ss for _ in range(nf)], l0, nl, has_nb, sin, sout,
                            [self.ck[s][k] for s in ss for k in range(nf)])
                 swept[d][i] = rec(chain)
@@ -406,8 +426,8 @@ class SlabEngine:
                     wait(bulk, swept[1][i])
             sg = [self.sigmas[s] for s in ss for _ in range(nf)]
             jobs = lambda bufs: [bufs[s][k] for s in ss for k in range(nf)]
-            st.z_combine([self.src[k] for s in ss for k in range(nf)], jobs(self.zo), sp, sg,
-                         has_lo, has_hi, jobs(self.ck))
+            st.z_combine([self.src[k] for s in ss for k in range(nf)], self.pad_lo, self.nzl,
+                         jobs(self.zo), sp, sg, has_lo, has_hi, jobs(self.ck))
             st.gaussian_axis_batch(jobs(self.zo), jobs(self.xo), sp, 0, sg)
             st.gaussian_axis_batch(jobs(self.xo), [self.pad[s][k][1:self.nzl + 1] for s in ss
                                                    for k in range(nf)], sp, 1, sg)
@@ -416,7 +436,8 @@ class SlabEngine:
                       [p[0] for p in pads], [p[self.nzl + 1] for p in pads])
             for s in ss:
                 st.features(self.pad[s][0][first:], self.pad[s][1][first:] if self.has_mask else None,
-                            mask_slab if self.has_mask else None, slab_shape, sp,
+                            mask_slab[self.pad_lo:self.pad_lo + self.nzl] if self.has_mask else None,
+                            slab_shape, sp,
                             1 if has_lo else 0, 1 if has_hi else 0, out[s], self.layout)
 
     def finish(self):
@@ -440,12 +461,14 @@ class SlabRunner:
         z0, nzl = bounds[rank], bounds[rank + 1] - bounds[rank]
         i16 = bool(getattr(args, "i16", False))
         spacing = tuple(getattr(args, "spacing", (1.0, 1.0, 1.0)))
-        img = (synth.volume_i16 if i16 else synth.volume_f32)((nzl, ny, nx), seed, z0=z0)
+        lo, hi = overlap(rank, world)  # the raw slab carries the neighbours' adjacent planes
+        ze, nze = z0 - lo, lo + nzl + hi
+        img = (synth.volume_i16 if i16 else synth.volume_f32)((nze, ny, nx), seed, z0=ze)
         if mask_kind == "ellipsoids":
-            mask = np.minimum(synth.mask_ellipsoids((nzl, ny, nx), z0=z0, nz_total=nz), 1)
+            mask = np.minimum(synth.mask_ellipsoids((nze, ny, nx), z0=ze, nz_total=nz), 1)
             mask = mask.astype(np.uint8)
         else:
-            mask = np.ones((nzl, ny, nx), np.uint8)
+            mask = np.ones((nze, ny, nx), np.uint8)
         self.d_img = torch.from_numpy(img).to(dev)
         self.d_mask = None if mask_kind == "none" else torch.from_numpy(mask).to(dev)
         oshape = ((len(sigmas), nzl, ny, nx, 8) if layout == pkg.INTERLEAVED

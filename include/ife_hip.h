@@ -233,11 +233,11 @@ int ife_mask_image_f64(ife_ctx *ctx, const double *image, const double *mask, do
  *
  * The reference runs the path in one address space (it has no
  * distributed code).  A multi-GPU host cuts the volume into Z-slabs, one per device, and
- * interposes two exchanges between these stages (image-feature-extraction_amd/slab.py,
- * DESIGN.md "Multi-GPU"): an all-to-all that turns Z-slabs into Y-slabs and back around
- * the Z pass (the only recursion that crosses slabs), and a one-plane halo exchange in
- * front of the stencil.  All pointers are device memory; calls enqueue on the context's
- * stream and do not synchronise. */
+ * interposes two neighbour exchanges between these stages (image-feature-extraction_amd/
+ * slab.py, csrc/multi_capi.inc, DESIGN.md "Multi-GPU"): the state of the Z recursion (the only
+ * one that crosses slabs) handed from slab to slab, 32 bytes per line and job, and a
+ * one-plane halo exchange in front of the stencil.  All pointers are device memory; calls
+ * enqueue on the context's stream and do not synchronise. */
 
 /* CastImageFilter + MultiplyImageFilter (ImageToEmphysemaFeaturesFilter.hxx:21,110;
  * NormalizedGaussianConvolutionImageFilter.hxx:48-49) on a slab: tc = float(image) *
@@ -276,9 +276,18 @@ int ife_stage_recursive_gaussian_batch(ife_ctx *ctx, int njobs, const float *con
  * Stitched over the slabs this is bit for bit the sequential recursion of the whole line.
  * Lines [line0, line0 + nlines) of the nx*ny lines are processed (x-fastest line index), so
  * that a host can pipeline groups of lines across devices.  A state buffer holds, per job,
- * 4*nlines doubles y[k][line] then 4*nlines floats x[k][line] (48*nlines bytes; 8-byte
- * aligned).  ck[job] points at ife_stage_z_ck_bytes(slab) bytes of device memory that must
- * survive from the sweeps to the combine.  Every slab needs at least 4 planes. */
+ * 4*nlines doubles y[k][line] (IFE_Z_STATE_BYTES * nlines bytes; 8-byte aligned): the last
+ * four outputs of the recursion, nearest first.  The INPUT samples a state refers to do not
+ * travel with it: where a neighbour exists, `in[job]` must be preceded by the neighbour's last
+ * 3 planes (has_lo / direction 0) and followed by its first 4 planes (has_hi / direction 1) --
+ * the slab's input is cut from the volume with that overlap (IFE_Z_OVERLAP_LO / _HI planes),
+ * which every device can do from its own copy of the raw data, and `in[job]` points at the
+ * slab's own plane 0 inside it.  ck[job] points at ife_stage_z_ck_bytes(slab) bytes of device
+ * memory that must survive from the sweeps to the combine.  Every slab needs at least 4
+ * planes. */
+#define IFE_Z_STATE_BYTES 32
+#define IFE_Z_OVERLAP_LO 3
+#define IFE_Z_OVERLAP_HI 4
 size_t ife_stage_z_ck_bytes(const ife_volume_desc *slab);
 int ife_stage_z_sweep(ife_ctx *ctx, int direction, int njobs, const float *const *in,
                       const ife_volume_desc *slab, int64_t line0, int64_t nlines,

@@ -52,22 +52,24 @@ class OracleStages:
 
     @staticmethod
     def _views(buf, nf, nl):
+        """Per job: [4][nl] doubles, the recursion's last four outputs (32 B per line)."""
         a = buf.numpy()
-        y = a[: nf * nl * 48].reshape(nf, nl * 48)
-        ys = [y[k, : nl * 32].view(np.float64).reshape(4, nl) for k in range(nf)]
-        xs = [y[k, nl * 32:].view(np.float32).reshape(4, nl) for k in range(nf)]
-        return ys, xs
+        y = a[: nf * nl * 32].reshape(nf, nl * 32)
+        return [y[k].view(np.float64).reshape(4, nl) for k in range(nf)]
 
-    def z_sweep(self, direction, srcs, spacing, sigmas, line0, nlines, has_neighbour, state_in,
-                state_out, cks):
-        nf = len(srcs)
-        nzl, ny, nx = srcs[0].shape
-        yo, xo = self._views(state_out, nf, nlines)
+    def z_sweep(self, direction, srcs_ext, pad_lo, nzl, spacing, sigmas, line0, nlines, has_neighbour,
+                state_in, state_out, cks):
+        """srcs_ext carry the neighbours' planes (slab.overlap): the x history of an incoming
+        state is read from them, only the y values travel."""
+        nf = len(srcs_ext)
+        _, ny, nx = srcs_ext[0].shape
+        yo = self._views(state_out, nf, nlines)
         if has_neighbour:
-            yi, xi = self._views(state_in, nf, nlines)
+            yi = self._views(state_in, nf, nlines)
         for k in range(nf):
             c = self.o.gauss_coeffs(sigmas[k], spacing[2])
-            x = srcs[k].numpy().reshape(nzl, ny * nx)[:, line0:line0 + nlines].astype(np.float64)
+            ext = srcs_ext[k].numpy().reshape(-1, ny * nx)[:, line0:line0 + nlines].astype(np.float64)
+            x = ext[pad_lo:pad_lo + nzl]
             out = np.empty_like(x)
             if direction == 0:
                 N = (c.N0, c.N1, c.N2, c.N3)
@@ -75,7 +77,7 @@ class OracleStages:
                 B = (c.BN1, c.BN2, c.BN3, c.BN4)
                 if has_neighbour:
                     yh = [yi[k][j].copy() for j in range(4)]          # y[i-1..i-4]
-                    xh = [xi[k][j].astype(np.float64) for j in range(3)]  # x[i-1..i-3]
+                    xh = [ext[pad_lo - 1 - j].copy() for j in range(3)]  # x[i-1..i-3]: the slab below
                 else:
                     yh = [x[0].copy() for _ in range(4)]
                     xh = [x[0].copy() for _ in range(3)]
@@ -89,16 +91,13 @@ class OracleStages:
                     yh = [y, yh[0], yh[1], yh[2]]
                 for j in range(4):
                     yo[k][j] = yh[j]
-                for j in range(3):
-                    xo[k][j] = xh[j].astype(np.float32)
-                xo[k][3] = 0
             else:
                 M = (c.M1, c.M2, c.M3, c.M4)
                 D = (c.D1, c.D2, c.D3, c.D4)
                 B = (c.BM1, c.BM2, c.BM3, c.BM4)
                 if has_neighbour:
-                    yh = [yi[k][j].copy() for j in range(4)]              # y[i+1..i+4]
-                    xh = [xi[k][j].astype(np.float64) for j in range(4)]  # x[i+1..i+4]
+                    yh = [yi[k][j].copy() for j in range(4)]                   # y[i+1..i+4]
+                    xh = [ext[pad_lo + nzl + j].copy() for j in range(4)]      # x[i+1..i+4]: the slab above
                 else:
                     yh = [x[nzl - 1].copy() for _ in range(4)]
                     xh = [x[nzl - 1].copy() for _ in range(4)]
@@ -112,10 +111,9 @@ class OracleStages:
                     yh = [y, yh[0], yh[1], yh[2]]
                 for j in range(4):
                     yo[k][j] = yh[j]
-                    xo[k][j] = xh[j].astype(np.float32)
             self.store[(cks[k].data_ptr(), direction, line0)] = out
 
-    def z_combine(self, srcs, dsts, spacing, sigmas, has_lo, has_hi, cks):
+    def z_combine(self, srcs_ext, pad_lo, nzl, dsts, spacing, sigmas, has_lo, has_hi, cks):
         import torch
         for k, dst in enumerate(dsts):
             nzl, ny, nx = dst.shape
@@ -169,8 +167,9 @@ def _worker(rank, world, port, shape, sigmas, spacing, use_hip, bounds, line_gro
         nz, ny, nx = shape
         b = bounds or slab.slab_bounds(nz, world)
         z0, nzl = b[rank], b[rank + 1] - b[rank]
-        img = synth.volume_f32((nzl, ny, nx), 77, z0=z0)
-        mask = np.minimum(synth.mask_ellipsoids((nzl, ny, nx), z0=z0, nz_total=nz), 1)
+        lo, hi = slab.overlap(rank, world)  # the raw slab with the neighbours' adjacent planes
+        img = synth.volume_f32((lo + nzl + hi, ny, nx), 77, z0=z0 - lo)
+        mask = np.minimum(synth.mask_ellipsoids((lo + nzl + hi, ny, nx), z0=z0 - lo, nz_total=nz), 1)
         mask = mask.astype(np.uint8)
         mask[:, :2, :] = 1
         streams = None
@@ -306,12 +305,20 @@ def test_z_slab_stage_kernels_match_single_device_pass(ife, oracle, synth):
     for bounds in ([0, 61], [0, 4, 61], [0, 25, 30, 61], [0, 13, 26, 39, 61]):
         W = len(bounds) - 1
         ctx = ife.Context(0)
-        slabs = [torch.from_numpy(vol[bounds[r]:bounds[r + 1]].copy()).cuda() for r in range(W)]
+        # every slab is cut with the neighbours' adjacent planes (3 below, 4 above): the x history
+        # of a state is read from them, the 32-byte records carry the y values only
+        slab_mod = importlib.import_module(PKG + ".slab")
+        ext, slabs = [], []
+        for r in range(W):
+            lo, hi = slab_mod.overlap(r, W)
+            e = torch.from_numpy(vol[bounds[r] - lo:bounds[r + 1] + hi].copy()).cuda()
+            ext.append(e)
+            slabs.append(e[lo:lo + bounds[r + 1] - bounds[r]])   # a view: data_ptr() is the slab's plane 0
         outs = [torch.empty_like(s) for s in slabs]
         cks = [torch.empty(ctx.stage_z_ck_bytes(tuple(s.shape)), dtype=torch.uint8, device="cuda")
                for s in slabs]
-        up = [torch.zeros(48 * L, dtype=torch.uint8, device="cuda") for _ in range(W)]
-        dn = [torch.zeros(48 * L, dtype=torch.uint8, device="cuda") for _ in range(W)]
+        up = [torch.zeros(ife.Z_STATE_BYTES * L, dtype=torch.uint8, device="cuda") for _ in range(W)]
+        dn = [torch.zeros(ife.Z_STATE_BYTES * L, dtype=torch.uint8, device="cuda") for _ in range(W)]
         for r in range(W):
             ctx.stage_z_sweep(0, [slabs[r].data_ptr()], tuple(slabs[r].shape), spacing, 0, L, [sigma],
                               r > 0, up[r - 1].data_ptr() if r > 0 else None, up[r].data_ptr(),
