@@ -85,10 +85,12 @@ class HipStages:
         return self.ctx.stage_z_ck_bytes(slab_shape)
 
     def prepare(self, img, mask, tc, cf):
+        """Runs with the boundary sweeps (chain context): the next step's prepass and sweeps
+        then overlap the bulk work of the current one."""
         pkg = self.pkg
         idt = pkg.F32 if img.element_size() == 4 else pkg.I16
         mdt = pkg.U8 if mask is None or mask.element_size() == 1 else pkg.U16
-        self.ctx.stage_prepare(img.data_ptr(), idt, mask.data_ptr() if mask is not None else None,
+        self.chain_ctx.stage_prepare(img.data_ptr(), idt, mask.data_ptr() if mask is not None else None,
                                mdt, tuple(img.shape), tc.data_ptr(),
                                cf.data_ptr() if cf is not None else None, 1)
 
@@ -340,12 +342,18 @@ class SlabEngine:
         self.schedule = sweep_schedule(rank, world, len(self.items))
         f = lambda *shp: alloc(shp, "float32")
         self.pad_lo, self.pad_hi = overlap(rank, world)
-        self.src = [f(self.pad_lo + nzl + self.pad_hi, ny, nx) for _ in range(nf)]  # tc, cf with overlap
+        # tc, cf with overlap, and the checkpoints: two sets, used by alternate steps, so that
+        # the prepass and the boundary sweeps of step t+1 (chain stream) may run while the bulk
+        # work of step t still reads its own -- in a stream of volumes the chains' start-up
+        # (W-1 hops) then hides behind the previous volume's X, Y and feature passes
+        self.src = [[f(self.pad_lo + nzl + self.pad_hi, ny, nx) for _ in range(nf)] for _ in range(2)]
         self.zo = [[f(nzl, ny, nx) for _ in range(nf)] for _ in range(S)]   # Z-pass output
         self.xo = [[f(nzl, ny, nx) for _ in range(nf)] for _ in range(S)]   # X-pass output
         self.pad = [[f(nzl + 2, ny, nx) for _ in range(nf)] for _ in range(S)]  # Y output + halo planes
         ckb = stages.ck_bytes((nzl, ny, nx))
-        self.ck = [[alloc((ckb,), "uint8") for _ in range(nf)] for _ in range(S)]
+        self.ck = [[[alloc((ckb,), "uint8") for _ in range(nf)] for _ in range(S)] for _ in range(2)]
+        self.step = 0
+        self.free = [None, None]  # events: the bulk work that read src[p] / ck[p] has been enqueued and run
         sb = lambda q, g: alloc((len(self.scale_groups[q]) * nf * STATE_BYTES_PER_LINE
                                  * self.groups[g][1],), "uint8")
         self.c_in = [sb(q, g) for q, g in self.items]
@@ -376,9 +384,9 @@ class SlabEngine:
         wait = (lambda s, e: sy.wait(s, e)) if sy is not None else (lambda s, e: None)
         n = len(self.items)
 
-        st.prepare(img_slab, mask_slab if self.has_mask else None, self.src[0],
-                   self.src[1] if self.has_mask else None)
-        prepared = rec(bulk)
+        par = self.step % 2
+        self.step += 1
+        src, ck = self.src[par], self.ck[par]
 
         # A receive is ENQUEUED where its sweep stands in the schedule, never earlier: the
         # schedule is a topological order of the whole job (every dependency has a smaller key
@@ -391,7 +399,9 @@ class SlabEngine:
         # still travels under the sweep of item i.
         swept = [[None] * n, [None] * n]
         with on(chain):
-            wait(chain, prepared)
+            wait(chain, self.free[par])  # the step before last has finished with this set
+            st.prepare(img_slab, mask_slab if self.has_mask else None, src[0],
+                       src[1] if self.has_mask else None)
             for d, i in self.schedule:
                 q, g = self.items[i]
                 ss = self.scale_groups[q]
@@ -407,9 +417,9 @@ class SlabEngine:
                 if self.sent[d][i] is not None:  # last step's send still reads sout
                     self.sent[d][i].wait()
                     self.sent[d][i] = None
-                st.z_sweep(d, [self.src[k] for _ in ss for k in range(nf)], self.pad_lo, self.nzl, sp,
+                st.z_sweep(d, [src[k] for _ in ss for k in range(nf)], self.pad_lo, self.nzl, sp,
                            [self.sigmas[s] for s in ss for _ in range(nf)], l0, nl, has_nb, sin, sout,
-                           [self.ck[s][k] for s in ss for k in range(nf)])
+                           [ck[s][k] for s in ss for k in range(nf)])
                 swept[d][i] = rec(chain)
                 self.consumed[d][i] = swept[d][i]
                 if d == 0 and has_hi:
@@ -426,8 +436,10 @@ class SlabEngine:
                     wait(bulk, swept[1][i])
             sg = [self.sigmas[s] for s in ss for _ in range(nf)]
             jobs = lambda bufs: [bufs[s][k] for s in ss for k in range(nf)]
-            st.z_combine([self.src[k] for s in ss for k in range(nf)], self.pad_lo, self.nzl,
-                         jobs(self.zo), sp, sg, has_lo, has_hi, jobs(self.ck))
+            st.z_combine([src[k] for s in ss for k in range(nf)], self.pad_lo, self.nzl,
+                         jobs(self.zo), sp, sg, has_lo, has_hi, jobs(ck))
+            if qs is self.bulk_groups[-1]:
+                self.free[par] = rec(bulk)  # the last reader of this step's src / ck set
             st.gaussian_axis_batch(jobs(self.zo), jobs(self.xo), sp, 0, sg)
             st.gaussian_axis_batch(jobs(self.xo), [self.pad[s][k][1:self.nzl + 1] for s in ss
                                                    for k in range(nf)], sp, 1, sg)
@@ -474,7 +486,9 @@ class SlabRunner:
         oshape = ((len(sigmas), nzl, ny, nx, 8) if layout == pkg.INTERLEAVED
                   else (len(sigmas), 8, nzl, ny, nx))
         self.d_out = torch.empty(oshape, dtype=torch.float32, device=dev)
-        self.streams = _Streams(torch, dev, two_streams=world > 1)
+        # the one-rank form (bench.py --force-slab: a rank's local work without neighbours) keeps
+        # the two streams of a real rank
+        self.streams = _Streams(torch, dev, two_streams=world > 1 or bool(getattr(args, "force_slab", False)))
         self.ctx = pkg.Context(dev.index or 0)
         self.ctx.set_stream(self.streams.bulk.cuda_stream)
         self.chain_ctx = self.ctx

@@ -227,7 +227,7 @@ def _whole_volume(synth, shape):
 @pytest.mark.parametrize("world,shape,spacing,bounds,groups,steps,spi,edge_groups", [
     (2, (16, 20, 12), (1.0, 1.0, 1.0), None, 1, 2, None, True),          # all scales in one item
     (3, (19, 40, 30), (1.0, 1.0, 1.0), [0, 4, 11, 19], 3, 1, 2, True),   # uneven cut, 3 line groups, scales 2 + 1
-    (4, (29, 24, 40), (0.8, 1.0, 1.25), None, 2, 2, 1, True),            # 8,7,7,7 planes, one scale per item
+    (4, (29, 24, 40), (0.8, 1.0, 1.25), None, 2, 3, 1, True),            # 8,7,7,7 planes, one scale per item; three steps: both buffer sets reused
     (4, (16, 20, 24), (1.0, 1.0, 1.0), None, 2, 2, 1, False),            # everything on the default group
     (8, (37, 16, 40), (1.0, 1.0, 1.0), None, None, 2, None, True),       # eight ranks, the engine's own defaults there
 ])
@@ -284,7 +284,7 @@ def test_slab_engine_on_gpu_equals_single_gpu(ife, synth, tmp_path, world, shape
     """HIP stages, two streams per rank, ranks sharing the one GPU: bit-identical to the
     single-GPU path (which is itself compared with the oracle elsewhere)."""
     sigmas, spacing = [1.0, 3.0, 2.0], (1.0, 1.0, 1.0)
-    got = _run_world(world, shape, sigmas, spacing, True, tmp_path, None, groups, 2)
+    got = _run_world(world, shape, sigmas, spacing, True, tmp_path, None, groups, 3)
     img, mask = _whole_volume(synth, shape)
     with ife.Context(0) as c:
         c.set_option(ife.OPT_TRIG_MODE, 0)
