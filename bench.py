@@ -54,8 +54,8 @@ SIMDS, SUSTAINED_GHZ = 1024, 2.03  # GRBM_GUI_ACTIVE / 8 / duration under this l
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)   # 0.2 s of device time; the first steps after
+    ap.add_argument("--warmup", type=int, default=5)   # start-up run 2 % slower (clocks settle)
     ap.add_argument("--size", type=int, nargs=3, default=[512, 512, 512], metavar=("NZ", "NY", "NX"))
     ap.add_argument("--sigmas", type=float, nargs="+", default=[1.0, 2.0, 4.0])
     ap.add_argument("--mask", choices=["ones", "ellipsoids", "none"], default="ones",
