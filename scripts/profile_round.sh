@@ -10,7 +10,7 @@ TAG=$1
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
-python3 "$ROOT/bench.py" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err" || tail -3 "$OUT/${TAG}_bench.err"
+python3 "$ROOT/bench.py" --steps 5 --warmup 2 > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err" || tail -3 "$OUT/${TAG}_bench.err"
 echo "bench done"
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG" -- \
    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-shortcut-leg > "$OUT/prof_$TAG.json" 2> "$OUT/prof_$TAG.err") \
