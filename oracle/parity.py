@@ -54,8 +54,11 @@ def eig_parity(got, ref, block=1 << 22):
         out["n"] += g.shape[0]
         if g.shape[1] >= 6:
             out["max_err_sum"] = max(out["max_err_sum"], float((np.abs(g[:, 3] - r[:, 3]) / lam).max()))
-            out["max_err_prod"] = max(out["max_err_prod"],
-                                      float((np.abs(g[:, 4] - r[:, 4]) / lam ** 3).max()))
+            # the product of three tiny eigenvalues lands among the float32 denormals, where one
+            # unit in the last place (1.4e-45) is no longer small against lambda_1^3: two such
+            # units are allowed before the relative bar applies
+            dp = np.maximum(np.abs(g[:, 4] - r[:, 4]) - 2.0 * 1.4012984643e-45, 0.0)
+            out["max_err_prod"] = max(out["max_err_prod"], float((dp / lam ** 3).max()))
             out["max_err_frob"] = max(out["max_err_frob"], float((np.abs(g[:, 5] - r[:, 5]) / lam).max()))
     return out
 
