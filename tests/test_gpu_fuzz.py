@@ -174,3 +174,36 @@ def test_random_configurations_of_the_other_entry_points(ctx, ife, oracle):
         assert float((d[..., 0:4] / lam[..., None]).max()) <= REL_TOL, what + " (a6 eigenvalues)"
         assert float((d[..., 5] / lam).max()) <= REL_TOL, what + " (a6 Frobenius)"
         assert float((d[..., 4] / lam ** 3).max()) <= 3 * REL_TOL, what + " (a6 product)"
+
+
+def test_random_configurations_of_the_multi_device_engine(ctx, ife):
+    """ife_multi with device 0 named 1-6 times (every slab, state record, overlap plane and
+    stencil plane of the W-device schedule on the one GPU) against the single-device path:
+    the same bits, for random shapes, cuts (nz not a multiple of W), scales, types and masks.
+    No oracle here: the single-device path is what the other sweeps pin."""
+    ncases = int(os.environ.get("IFE_FUZZ_CASES", "24"))
+    rng = np.random.default_rng(int(os.environ.get("IFE_FUZZ_SEED", "20261004")) + 3)
+    engines = {}
+    try:
+        for case in range(ncases):
+            shape, spacing, sig = _draw_case(rng)
+            W = int(rng.integers(1, 7))
+            if shape[0] < 4 * W:
+                shape = (4 * W + int(rng.integers(0, 6)),) + shape[1:]
+            if rng.random() < 0.3:
+                sig = sig + [float(np.float32(s * 1.7)) for s in sig] + [sig[0] * 0.5 + 0.4]   # two scale groups
+            i16 = rng.random() < 0.3
+            img = _draw_volume(rng, shape, i16)
+            mask = _draw_mask(rng, shape)
+            layout = ife.INTERLEAVED if rng.random() < 0.7 else ife.PLANAR
+            what = "case %d: W %d shape %s spacing %s sigma %s %s mask %s layout %d" % (
+                case, W, shape, spacing, sig, img.dtype, None if mask is None else mask.dtype, layout)
+            if W not in engines:
+                engines[W] = ife.Multi([0] * W)
+                engines[W].set_option(ife.OPT_TRIG_MODE, 0)
+            got = engines[W].emphysema_features(img, mask, sig, spacing, layout)
+            ref = ctx.emphysema_features(img, mask, sig, spacing, layout)
+            np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32), err_msg=what)
+    finally:
+        for m in engines.values():
+            m.close()
