@@ -207,14 +207,21 @@ int drain_profile(ife_ctx *ctx) {
 // ---- recursive Gaussian coefficients ------------------------------------------------
 // [ITK-upstream] itk::RecursiveGaussianImageFilter::SetUp, ZeroOrder,
 // NormalizeAcrossScale off.  Host-side, double.
+// sin and cos of the pole angles through ONE sincos call, as GCC compiles ITK's adjacent
+// std::sin / std::cos: glibc's sincos and cos differ in the last bit for some arguments, and
+// 1 + sum(D) amplifies that to one float ulp of an output at one sample in 10^8-10^9
+// (oracle/ife_oracle.c: pole_sincos; found by tests/test_gpu_fuzz.py).
+void pole_sincos(double x, double &s, double &c) { ::sincos(x, &s, &c); }
+
 int gauss_coeffs(double sigma, double spacing, IirCoef *c) {
   const double A1 = 1.3530, B1 = 1.8151, W1 = 0.6681, L1 = -1.3932;
   const double A2 = -0.3531, B2 = 0.0902, W2 = 2.0787, L2 = -1.3732;
   if (spacing < 0.0) spacing = -spacing;
   if (spacing < 1e-8) return -1;
   const double sd = sigma / spacing;
-  const double Sin1 = std::sin(W1 / sd), Sin2 = std::sin(W2 / sd);
-  const double Cos1 = std::cos(W1 / sd), Cos2 = std::cos(W2 / sd);
+  double Sin1, Sin2, Cos1, Cos2;
+  pole_sincos(W1 / sd, Sin1, Cos1);
+  pole_sincos(W2 / sd, Sin2, Cos2);
   const double Exp1 = std::exp(L1 / sd), Exp2 = std::exp(L2 / sd);
   c->D4 = Exp1 * Exp1 * Exp2 * Exp2;
   c->D3 = -2 * Cos1 * Exp1 * Exp2 * Exp2;
@@ -257,8 +264,9 @@ int gauss_coeffs(double sigma, double spacing, IirCoef *c) {
 void n_coefficients(double sd, double A1, double B1, double W1, double L1, double A2, double B2,
                     double W2, double L2, double &N0, double &N1, double &N2, double &N3, double &SN,
                     double &DN, double &EN) {
-  const double Sin1 = std::sin(W1 / sd), Sin2 = std::sin(W2 / sd);
-  const double Cos1 = std::cos(W1 / sd), Cos2 = std::cos(W2 / sd);
+  double Sin1, Sin2, Cos1, Cos2;
+  pole_sincos(W1 / sd, Sin1, Cos1);
+  pole_sincos(W2 / sd, Sin2, Cos2);
   const double Exp1 = std::exp(L1 / sd), Exp2 = std::exp(L2 / sd);
   N0 = A1 + A2;
   N1 = Exp2 * (B2 * Sin2 - (A2 + 2 * A1) * Cos2);
@@ -284,7 +292,10 @@ int gauss_coeffs_order(double sigma, double spacing, int order, IirCoef *c) {
   if (spacing < 1e-8) return -1;
   const double sd = sigma / spacing;
   {
-    const double Cos1 = std::cos(W1 / sd), Cos2 = std::cos(W2 / sd);
+    double Sin1, Sin2, Cos1, Cos2;
+    pole_sincos(W1 / sd, Sin1, Cos1);
+    pole_sincos(W2 / sd, Sin2, Cos2);
+    (void)Sin1; (void)Sin2;
     const double Exp1 = std::exp(L1 / sd), Exp2 = std::exp(L2 / sd);
     c->D4 = Exp1 * Exp1 * Exp2 * Exp2;
     c->D3 = -2 * Cos1 * Exp1 * Exp2 * Exp2;

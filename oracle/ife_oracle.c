@@ -1,3 +1,4 @@
+#define _GNU_SOURCE /* sincos */
 /*
  * ife_oracle.c -- CPU restatement (plain C) of the reference's per-voxel Hessian
  * feature path.  TEST INFRASTRUCTURE ONLY: see ife_oracle.h for who may load it
@@ -144,6 +145,18 @@ void ife_or_eig3_batch_f64(const double *A6, int64_t n, double *ev3) {
   for (int64_t i = 0; i < n; ++i) ife_or_eig3_f64(A6 + 6 * i, ev3 + 3 * i);
 }
 
+/* sin and cos of the filter's pole angles.  ITK writes std::sin(x) and std::cos(x) side by
+ * side (itkRecursiveGaussianImageFilter.hxx, ComputeNCoefficients / ComputeDCoefficients); GCC,
+ * the compiler of the reference's Linux build, turns such a pair into ONE sincos(x) call, and
+ * glibc's sincos differs from its cos in the last bit for some arguments (W1 / sigma_d with
+ * sigma_d = 9.92: 0x1.fed70ab75a41dp-1 against ...41cp-1).  The cancellation in 1 + sum(D)
+ * amplifies that bit to 1e-13 of an output sample, i.e. to one float ulp at about one sample
+ * in 10^8-10^9.  Both sides of the parity tests therefore call sincos explicitly: which of
+ * the two a build gets no longer depends on a compiler's optimiser (found by
+ * tests/test_gpu_fuzz.py: the device library's host code is compiled by clang, which keeps
+ * the two calls apart). */
+static void pole_sincos(double x, double *s, double *c) { sincos(x, s, c); }
+
 /* ------------------------------------------------------------------------- */
 /* a4 pieces [ITK-upstream, parity unpinned]: itk::RecursiveGaussianImageFilter */
 /* ::SetUp / ComputeNCoefficients / ComputeDCoefficients /                      */
@@ -158,7 +171,10 @@ int ife_or_gauss_coeffs_zero_order(double sigma, double spacing, ife_or_gauss_co
   const double sigmad = sigma / spacing;
 
   {
-    const double Cos1 = cos(W1 / sigmad), Cos2 = cos(W2 / sigmad);
+    double Sin1, Sin2, Cos1, Cos2;
+    pole_sincos(W1 / sigmad, &Sin1, &Cos1);
+    pole_sincos(W2 / sigmad, &Sin2, &Cos2);
+    (void)Sin1; (void)Sin2;
     const double Exp1 = exp(L1 / sigmad), Exp2 = exp(L2 / sigmad);
     c->D4 = Exp1 * Exp1 * Exp2 * Exp2;
     c->D3 = -2 * Cos1 * Exp1 * Exp2 * Exp2;
@@ -170,8 +186,9 @@ int ife_or_gauss_coeffs_zero_order(double sigma, double spacing, ife_or_gauss_co
   const double SD = 1.0 + c->D1 + c->D2 + c->D3 + c->D4;
   double SN;
   {
-    const double Sin1 = sin(W1 / sigmad), Sin2 = sin(W2 / sigmad);
-    const double Cos1 = cos(W1 / sigmad), Cos2 = cos(W2 / sigmad);
+    double Sin1, Sin2, Cos1, Cos2;
+    pole_sincos(W1 / sigmad, &Sin1, &Cos1);
+    pole_sincos(W2 / sigmad, &Sin2, &Cos2);
     const double Exp1 = exp(L1 / sigmad), Exp2 = exp(L2 / sigmad);
     c->N0 = A1 + A2;
     c->N1 = Exp2 * (B2 * Sin2 - (A2 + 2 * A1) * Cos2);
@@ -269,8 +286,9 @@ void ife_or_iir_line(const double *data, double *outs, double *s, int64_t ln,
 static void n_coefficients(double sigmad, double A1, double B1, double W1, double L1, double A2,
                            double B2, double W2, double L2, double *N0, double *N1, double *N2,
                            double *N3, double *SN, double *DN, double *EN) {
-  const double Sin1 = sin(W1 / sigmad), Sin2 = sin(W2 / sigmad);
-  const double Cos1 = cos(W1 / sigmad), Cos2 = cos(W2 / sigmad);
+  double Sin1, Sin2, Cos1, Cos2;
+  pole_sincos(W1 / sigmad, &Sin1, &Cos1);
+  pole_sincos(W2 / sigmad, &Sin2, &Cos2);
   const double Exp1 = exp(L1 / sigmad), Exp2 = exp(L2 / sigmad);
   *N0 = A1 + A2;
   *N1 = Exp2 * (B2 * Sin2 - (A2 + 2 * A1) * Cos2);
@@ -297,7 +315,10 @@ int ife_or_gauss_coeffs_order(double sigma, double spacing, int order, ife_or_ga
   if (spacing < 1e-8) return -1;
   const double sigmad = sigma / spacing;
   {
-    const double Cos1 = cos(W1 / sigmad), Cos2 = cos(W2 / sigmad);
+    double Sin1, Sin2, Cos1, Cos2;
+    pole_sincos(W1 / sigmad, &Sin1, &Cos1);
+    pole_sincos(W2 / sigmad, &Sin2, &Cos2);
+    (void)Sin1; (void)Sin2;
     const double Exp1 = exp(L1 / sigmad), Exp2 = exp(L2 / sigmad);
     c->D4 = Exp1 * Exp1 * Exp2 * Exp2;
     c->D3 = -2 * Cos1 * Exp1 * Exp2 * Exp2;
