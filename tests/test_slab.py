@@ -293,6 +293,40 @@ def test_slab_engine_on_gpu_equals_single_gpu(ife, synth, tmp_path, world, shape
 
 
 @pytest.mark.gpu
+def test_slab_engine_on_gpu_random_configurations(ife, synth, tmp_path):
+    """The Python engine (what bench.py runs at N > 1) on drawn configurations: 2-5 ranks sharing
+    the GPU, awkward shapes, uneven cuts, 1-5 line groups, one or all scales per item, two or
+    three steps -- identical bits to the single-GPU path.  IFE_FUZZ_CASES / 6 cases (default 4)."""
+    ncases = max(1, int(os.environ.get("IFE_FUZZ_CASES", "24")) // 6)
+    rng = np.random.default_rng(int(os.environ.get("IFE_FUZZ_SEED", "20261004")) + 7)
+    for case in range(ncases):
+        world = int(rng.integers(2, 6))
+        ny, nx = int(rng.choice([4, 9, 20, 33, 64, 70])), int(rng.choice([4, 12, 31, 64, 100]))
+        nz = 4 * world + int(rng.integers(0, 40))
+        cuts = sorted(rng.choice(np.arange(1, nz // 4), world - 1, replace=False).tolist()) if rng.random() < 0.5 else None
+        bounds = None
+        if cuts is not None:                       # uneven cut, every slab at least 4 planes
+            b = [0] + [4 * c for c in cuts] + [nz]
+            if min(y - x for x, y in zip(b, b[1:])) >= 4:
+                bounds = b
+        sigmas = [float(np.float32(x)) for x in rng.uniform(0.7, 3.5, int(rng.integers(1, 4)))]
+        spacing = (1.0, 1.0, 1.0) if rng.random() < 0.5 else tuple(float(x) for x in rng.uniform(0.6, 1.8, 3))
+        groups = int(rng.integers(1, 6))
+        spi = None if rng.random() < 0.5 else 1
+        steps = int(rng.integers(2, 4))
+        sub = tmp_path / ("case%d" % case)
+        sub.mkdir()
+        what = "case %d: world %d shape %s bounds %s sigmas %s spacing %s groups %d spi %s steps %d" % (
+            case, world, (nz, ny, nx), bounds, sigmas, spacing, groups, spi, steps)
+        got = _run_world(world, (nz, ny, nx), sigmas, spacing, True, sub, bounds, groups, steps, spi)
+        img, mask = _whole_volume(synth, (nz, ny, nx))
+        with ife.Context(0) as c:
+            c.set_option(ife.OPT_TRIG_MODE, 0)
+            ref = c.emphysema_features(img, mask, sigmas, spacing)
+        np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32), err_msg=what)
+
+
+@pytest.mark.gpu
 def test_z_slab_stage_kernels_match_single_device_pass(ife, oracle, synth):
     """The three slab kernels on their own: a volume cut into slabs of awkward sizes, states
     handed over in host order, equals the oracle's Z pass bit for bit."""
