@@ -207,3 +207,46 @@ def test_random_configurations_of_the_multi_device_engine(ctx, ife):
     finally:
         for m in engines.values():
             m.close()
+
+
+def test_random_configurations_of_the_fused_sampling(ctx, ife, oracle):
+    """Row f1's front end: ife_samples_add_image (features written straight into the sample
+    columns of the foreground voxels, raster order) on drawn shapes -- ragged row segments,
+    sparse and dense label maps of uint8 / uint16, label sets with and without 0, one or two
+    scales, anisotropic spacing -- against the oracle's features gathered on the CPU."""
+    ncases = max(1, int(os.environ.get("IFE_FUZZ_CASES", "24")) // 2)
+    rng = np.random.default_rng(int(os.environ.get("IFE_FUZZ_SEED", "20261004")) + 5)
+    for case in range(ncases):
+        shape, spacing, sig = _draw_case(rng)
+        img = _draw_volume(rng, shape, False)
+        nlab = int(rng.integers(2, 5))
+        p0 = float(rng.choice([0.2, 0.7, 0.98]))
+        lab = np.where(rng.random(shape) < p0, 0, rng.integers(1, nlab, shape)).astype(
+            np.uint8 if rng.random() < 0.6 else np.uint16)
+        if lab.dtype == np.uint16:
+            lab = lab * 257
+        values = np.unique(lab)
+        fg = tuple(int(v) for v in rng.choice(values, int(rng.integers(1, len(values) + 1)), replace=False))
+        what = "case %d: shape %s spacing %s sigma %s labels %s %s foreground %s" % (
+            case, shape, spacing, sig, lab.dtype, values.tolist(), fg)
+        clamped = np.minimum(lab, 1).astype(np.uint8)
+        s = ctx.samples(8 * len(sig))
+        try:
+            s.add_image(img, lab, sig, foreground=fg, spacing=spacing)
+            sel = np.isin(lab, fg)
+            assert s.count(0) == int(sel.sum()), what
+            for k, sigma in enumerate(sig):
+                f = oracle.emphysema_features(img, clamped, sigma, spacing)
+                lam = np.maximum(np.abs(f[..., 2][sel]).astype(np.float64), 1e-30)
+                for c in range(8):
+                    want, got = f[..., c][sel], s.column(8 * k + c)
+                    nan = np.isnan(want)
+                    assert np.array_equal(np.isnan(got), nan), what
+                    want, got = np.where(nan, 0, want), np.where(nan, 0, got)
+                    if c < 2:
+                        assert np.array_equal(got, want), (what, c)
+                    elif sel.any():
+                        e = np.abs(got.astype(np.float64) - want) / lam ** (3 if c == 6 else 1)
+                        assert e.max() <= 3 * REL_TOL, (what, c, float(e.max()))
+        finally:
+            s.close()
