@@ -10,9 +10,12 @@ left in HBM.
 
   value = nx*ny*nz * n_scales / t_step / 1e6          [Mvoxels/s, "voxel-scales"]
 
-Launch: `python bench.py --gpus 1`, or for N>1
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
-Prints ONE JSON line on rank 0.
+Launch: `python bench.py --gpus 1`; for N>1 either
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (the ranks read
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or plain
+`python bench.py --gpus N`: with no WORLD_SIZE in the environment the process becomes a
+launcher that never touches the GPU, starts the N ranks as child processes, relays rank 0's
+line and exits with the worst exit code (launch_ranks).  Prints ONE JSON line.
 """
 import argparse
 import importlib
@@ -81,6 +84,8 @@ def parse():
                          "headline (the profiling scripts use it: every profiled launch is a headline launch)")
     ap.add_argument("--no-fused-divide", action="store_true",
                     help="IFE_OPT_FUSED_DIVIDE=0: two fields out of the last axis pass (A/B)")
+    ap.add_argument("--feat-ring", type=int, default=1, choices=[0, 1],
+                    help="IFE_OPT_FEAT_RING (A/B): 1 planes by LDS-DMA into a ring (default), 0 register-staged")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-slab", action="store_true",
                     help="run the Z-slab engine (RCCL exchanges) even with one rank")
@@ -89,7 +94,91 @@ def parse():
                     help="N>1: scales whose boundary sweeps share a launch and a message (slab.py)")
     ap.add_argument("--line-groups", type=int, default=None,
                     help="N>1: items per scale on the boundary-state chains (slab.py)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher rehearsal without a GPU: the ranks meet over gloo, agree on a "
+                         "sum and rank 0 prints a stub line (tests/test_bench_launch.py)")
+    ap.add_argument("--launch-timeout", type=float, default=900.0,
+                    help="self-launch: seconds after which the launcher ends its ranks")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves.
+
+    This process makes no GPU call (it never imports torch): a parent that had initialised
+    the GPU could not hand it to its children.  Each rank is a fresh interpreter running this
+    file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, exactly what
+    torch.distributed.run would give it.  Rank 0's stdout is the job's stdout (one JSON
+    line); every rank's stderr passes through.  A rank that fails takes the others down (they
+    would otherwise sit in a collective until the process-group timeout), and the launcher's
+    exit code is the worst of the ranks'."""
+    import socket
+    import subprocess
+    n = args.gpus
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in env:
+        with socket.socket() as sk:  # a free port of this host
+            sk.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(sk.getsockname()[1])
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
+    env.setdefault("GPU_MAX_HW_QUEUES", "16")  # see the top of this file
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stdin=subprocess.DEVNULL, text=True))
+    deadline = time.time() + args.launch_timeout
+    codes = [None] * n
+    failed = False
+    while any(c is None for c in codes):
+        for r, pr in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = pr.poll()
+                if codes[r] not in (None, 0):
+                    failed = True
+        if failed or time.time() > deadline:
+            for r, pr in enumerate(procs):  # exactly the processes started here, by pid
+                if codes[r] is None:
+                    pr.terminate()
+            t_end = time.time() + 10
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = pr.wait(timeout=max(0.1, t_end - time.time()))
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        codes[r] = pr.wait()
+                    if not failed:
+                        codes[r] = codes[r] or 124  # ended by the launcher's timeout
+            break
+        time.sleep(0.05)
+    out = procs[0].stdout.read() if procs[0].stdout else ""
+    for ln in out.splitlines():  # the contract is ONE line: library banners go to stderr
+        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln + "\n")
+    sys.stdout.flush()
+    worst = max((abs(c) for c in codes if c), default=0)
+    if worst:
+        sys.stderr.write("bench.py launcher: rank exit codes %s\n" % codes)
+    return worst if worst < 256 else 1
+
+
+def dry_launch_rank(args):
+    """Launcher rehearsal (no GPU): rendezvous over gloo, one all-reduce, one line."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "rank_sum": t.item(),
+                          "local_ranks": "0..%d" % (world - 1)}), flush=True)
+    dist.destroy_process_group()
 
 
 def cpu_baseline(synth, seed, sigmas, edge):
@@ -140,6 +229,10 @@ def measured_copy_gbs(torch, dev, nbytes=1 << 30, reps=5):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))  # before anything touches the GPU
+    if args.dry_launch:
+        return dry_launch_rank(args)
     import torch
     import torch.distributed as dist
 
@@ -147,7 +240,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run"
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (unset WORLD_SIZE to let bench.py start its own ranks)"
                          % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -344,6 +437,7 @@ class SingleGpuRunner:
         if args.no_fused_divide:
             self.ctx.set_option(pkg.OPT_FUSED_DIVIDE, 0)
         self.ctx.set_option(pkg.OPT_CONST_LINES, args.const_lines)
+        self.ctx.set_option(pkg.OPT_FEAT_RING, args.feat_ring)
         self.ctx.reserve(shape)
         self.config = {"input": "int16" if args.i16 else "float32", "spacing": list(self.spacing)}
 

@@ -28,6 +28,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 OPT_TRIG_MODE, OPT_DSCALE_MODE, OPT_PROFILE, OPT_ZCHUNK, OPT_IIR_BLOCK, OPT_IIR_CKPT, OPT_IIR_FMA = 1, 2, 3, 4, 5, 6, 7
 OPT_FUSED_DIVIDE = 8
 OPT_CONST_LINES = 9
+OPT_FEAT_RING = 10
 Z_STATE_BYTES = 32   # IFE_Z_STATE_BYTES: one state record of the slab Z pass, per line and job
 Z_OVERLAP_LO, Z_OVERLAP_HI = 3, 4  # IFE_Z_OVERLAP_*: neighbour planes around a slab's input
 NUM_FEATURES = 8

@@ -138,6 +138,102 @@ constexpr int FT_NE = FT_HX * FT_HY;  // staged elements per plane (tile + halo)
 constexpr int FT_THREADS = FT_TX * FT_TY;
 constexpr int FT_NLD = (FT_NE + FT_THREADS - 1) / FT_THREADS;  // staged elements per thread
 
+// The arithmetic of one voxel: its 19 stencil points from the three staged planes (row pitch
+// FT_HX, one-voxel halo) to the NOUT outputs of MODE, before masking.  Shared by both forms
+// of the feature kernel, so that they cannot differ in a rounding.
+template <int MODE, bool UNIT, int TRIG, bool KLDS>
+__device__ __forceinline__ void feat_point(const float (*tm)[FT_HX], const float (*t0)[FT_HX],
+                                           const float (*tp)[FT_HX], int ty, int tx,
+                                           const DerivCoef &dc, const double *ktab,
+                                           float (&o)[FeatNOut<MODE>::value]) {
+  constexpr bool F8 = MODE == FEAT_FEATURES8 || MODE == FEAT_SAMPLES8;
+  constexpr bool NEED_H = MODE != FEAT_GRADMAG;
+  constexpr bool NEED_G = F8 || MODE == FEAT_GRADMAG;
+  const float c = t0[ty + 1][tx + 1];
+  const float xm = t0[ty + 1][tx], xp = t0[ty + 1][tx + 2];
+  const float ym = t0[ty][tx + 1], yp = t0[ty + 2][tx + 1];
+  const float zm = tm[ty + 1][tx + 1], zp = tp[ty + 1][tx + 1];
+  float G = 0.0f;
+  if (NEED_G) {
+    double gx, gy, gz;
+    if (UNIT) {
+      gx = 0.5 * ((double)xp - (double)xm);
+      gy = 0.5 * ((double)yp - (double)ym);
+      gz = 0.5 * ((double)zp - (double)zm);
+    } else {
+      gx = d1(dc.m1[0], dc.p1[0], xm, xp);
+      gy = d1(dc.m1[1], dc.p1[1], ym, yp);
+      gz = d1(dc.m1[2], dc.p1[2], zm, zp);
+    }
+    double a = gx * gx;
+    a += gy * gy;
+    a += gz * gz;
+#if defined(IFE_DIAG_NO_GSQRT)
+    G = (float)a;
+#else
+    G = (float)sqrt(a);
+#endif
+  }
+  if constexpr (MODE == FEAT_GRADMAG) {
+    o[0] = G;
+  } else if (NEED_H) {
+    // first differences as float images at the six neighbours, then chained
+    const float cmm = t0[ty][tx], cpm = t0[ty][tx + 2];
+    const float cmp = t0[ty + 2][tx], cpp = t0[ty + 2][tx + 2];
+    const float zm_xm = tm[ty + 1][tx], zm_xp = tm[ty + 1][tx + 2];
+    const float zm_ym = tm[ty][tx + 1], zm_yp = tm[ty + 2][tx + 1];
+    const float zp_xm = tp[ty + 1][tx], zp_xp = tp[ty + 1][tx + 2];
+    const float zp_ym = tp[ty][tx + 1], zp_yp = tp[ty + 2][tx + 1];
+    float dxx, dyy, dzz, dxy, dxz, dyz;
+    if (UNIT) {
+      const float dx_ym = 0.5f * (cpm - cmm), dx_yp = 0.5f * (cpp - cmp);
+      const float dx_zm = 0.5f * (zm_xp - zm_xm), dx_zp = 0.5f * (zp_xp - zp_xm);
+      const float dy_zm = 0.5f * (zm_yp - zm_ym), dy_zp = 0.5f * (zp_yp - zp_ym);
+      dxy = 0.5f * (dx_yp - dx_ym);
+      dxz = 0.5f * (dx_zp - dx_zm);
+      dyz = 0.5f * (dy_zp - dy_zm);
+      const double cd = (double)c;
+      dxx = (float)(fma(-2.0, cd, (double)xm) + (double)xp);
+      dyy = (float)(fma(-2.0, cd, (double)ym) + (double)yp);
+      dzz = (float)(fma(-2.0, cd, (double)zm) + (double)zp);
+    } else {
+      const float dx_ym = (float)d1(dc.m1[0], dc.p1[0], cmm, cpm);
+      const float dx_yp = (float)d1(dc.m1[0], dc.p1[0], cmp, cpp);
+      const float dx_zm = (float)d1(dc.m1[0], dc.p1[0], zm_xm, zm_xp);
+      const float dx_zp = (float)d1(dc.m1[0], dc.p1[0], zp_xm, zp_xp);
+      const float dy_zm = (float)d1(dc.m1[1], dc.p1[1], zm_ym, zm_yp);
+      const float dy_zp = (float)d1(dc.m1[1], dc.p1[1], zp_ym, zp_yp);
+      dxy = (float)d1(dc.m1[1], dc.p1[1], dx_ym, dx_yp);
+      dxz = (float)d1(dc.m1[2], dc.p1[2], dx_zm, dx_zp);
+      dyz = (float)d1(dc.m1[2], dc.p1[2], dy_zm, dy_zp);
+      dxx = d2(dc.a2[0], dc.b2[0], dc.c2[0], xm, c, xp);
+      dyy = d2(dc.a2[1], dc.b2[1], dc.c2[1], ym, c, yp);
+      dzz = d2(dc.a2[2], dc.b2[2], dc.c2[2], zm, c, zp);
+    }
+    if constexpr (MODE == FEAT_HESSIAN6) {
+      o[0] = dxx; o[1] = dxy; o[2] = dxz; o[3] = dyy; o[4] = dyz; o[5] = dzz;
+    } else {
+      EigFeat ef;
+#if defined(IFE_DIAG_NO_SOLVER)  // timing diagnostics only: results are wrong by construction
+      ef.f[0] = dxx; ef.f[1] = dxy; ef.f[2] = dxz; ef.f[3] = dyy; ef.f[4] = dyz; ef.f[5] = dzz;
+#else
+      if constexpr (KLDS)
+        ef = eig_features<TRIG>(dxx, dxy, dxz, dyy, dyz, dzz, EigConstLds::at(ktab));
+      else
+        ef = eig_features<TRIG>(dxx, dxy, dxz, dyy, dyz, dzz);
+#endif
+      if constexpr (F8) {
+        o[0] = c; o[1] = G;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[2 + k] = ef.f[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[k] = ef.f[k];
+      }
+    }
+  }
+}
+
 // One workgroup owns a 64 x FT_TY XY tile and marches along z.  Four LDS slots hold the
 // tile (with replicate halo) of planes z-1, z, z+1 and the plane being written for the
 // next step, so one barrier per plane suffices; a thread reads its 19 stencil points
@@ -346,92 +442,8 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES(MODE, UNIT, TRIG)) void fe
     // A wave whose 64 voxels are all outside the mask skips the arithmetic (scalar branch);
     // otherwise every lane computes and masked lanes are zeroed at the end.
     if (__builtin_amdgcn_ballot_w64(keep) != 0) {
-      const float(*tm)[FT_HX] = tile[(z - 1 - (z0 - 1)) & 3];
-      const float(*t0)[FT_HX] = tile[(z - (z0 - 1)) & 3];
-      const float(*tp)[FT_HX] = tile[(z + 1 - (z0 - 1)) & 3];
-      const float c = t0[ty + 1][tx + 1];
-      const float xm = t0[ty + 1][tx], xp = t0[ty + 1][tx + 2];
-      const float ym = t0[ty][tx + 1], yp = t0[ty + 2][tx + 1];
-      const float zm = tm[ty + 1][tx + 1], zp = tp[ty + 1][tx + 1];
-      float G = 0.0f;
-      if (NEED_G) {
-        double gx, gy, gz;
-        if (UNIT) {
-          gx = 0.5 * ((double)xp - (double)xm);
-          gy = 0.5 * ((double)yp - (double)ym);
-          gz = 0.5 * ((double)zp - (double)zm);
-        } else {
-          gx = d1(dc.m1[0], dc.p1[0], xm, xp);
-          gy = d1(dc.m1[1], dc.p1[1], ym, yp);
-          gz = d1(dc.m1[2], dc.p1[2], zm, zp);
-        }
-        double a = gx * gx;
-        a += gy * gy;
-        a += gz * gz;
-#if defined(IFE_DIAG_NO_GSQRT)
-        G = (float)a;
-#else
-        G = (float)sqrt(a);
-#endif
-      }
-      if constexpr (MODE == FEAT_GRADMAG) {
-        o[0] = G;
-      } else if (NEED_H) {
-        // first differences as float images at the six neighbours, then chained
-        const float cmm = t0[ty][tx], cpm = t0[ty][tx + 2];
-        const float cmp = t0[ty + 2][tx], cpp = t0[ty + 2][tx + 2];
-        const float zm_xm = tm[ty + 1][tx], zm_xp = tm[ty + 1][tx + 2];
-        const float zm_ym = tm[ty][tx + 1], zm_yp = tm[ty + 2][tx + 1];
-        const float zp_xm = tp[ty + 1][tx], zp_xp = tp[ty + 1][tx + 2];
-        const float zp_ym = tp[ty][tx + 1], zp_yp = tp[ty + 2][tx + 1];
-        float dxx, dyy, dzz, dxy, dxz, dyz;
-        if (UNIT) {
-          const float dx_ym = 0.5f * (cpm - cmm), dx_yp = 0.5f * (cpp - cmp);
-          const float dx_zm = 0.5f * (zm_xp - zm_xm), dx_zp = 0.5f * (zp_xp - zp_xm);
-          const float dy_zm = 0.5f * (zm_yp - zm_ym), dy_zp = 0.5f * (zp_yp - zp_ym);
-          dxy = 0.5f * (dx_yp - dx_ym);
-          dxz = 0.5f * (dx_zp - dx_zm);
-          dyz = 0.5f * (dy_zp - dy_zm);
-          const double cd = (double)c;
-          dxx = (float)(fma(-2.0, cd, (double)xm) + (double)xp);
-          dyy = (float)(fma(-2.0, cd, (double)ym) + (double)yp);
-          dzz = (float)(fma(-2.0, cd, (double)zm) + (double)zp);
-        } else {
-          const float dx_ym = (float)d1(dc.m1[0], dc.p1[0], cmm, cpm);
-          const float dx_yp = (float)d1(dc.m1[0], dc.p1[0], cmp, cpp);
-          const float dx_zm = (float)d1(dc.m1[0], dc.p1[0], zm_xm, zm_xp);
-          const float dx_zp = (float)d1(dc.m1[0], dc.p1[0], zp_xm, zp_xp);
-          const float dy_zm = (float)d1(dc.m1[1], dc.p1[1], zm_ym, zm_yp);
-          const float dy_zp = (float)d1(dc.m1[1], dc.p1[1], zp_ym, zp_yp);
-          dxy = (float)d1(dc.m1[1], dc.p1[1], dx_ym, dx_yp);
-          dxz = (float)d1(dc.m1[2], dc.p1[2], dx_zm, dx_zp);
-          dyz = (float)d1(dc.m1[2], dc.p1[2], dy_zm, dy_zp);
-          dxx = d2(dc.a2[0], dc.b2[0], dc.c2[0], xm, c, xp);
-          dyy = d2(dc.a2[1], dc.b2[1], dc.c2[1], ym, c, yp);
-          dzz = d2(dc.a2[2], dc.b2[2], dc.c2[2], zm, c, zp);
-        }
-        if constexpr (MODE == FEAT_HESSIAN6) {
-          o[0] = dxx; o[1] = dxy; o[2] = dxz; o[3] = dyy; o[4] = dyz; o[5] = dzz;
-        } else {
-          EigFeat ef;
-#if defined(IFE_DIAG_NO_SOLVER)  // timing diagnostics only: results are wrong by construction
-          ef.f[0] = dxx; ef.f[1] = dxy; ef.f[2] = dxz; ef.f[3] = dyy; ef.f[4] = dyz; ef.f[5] = dzz;
-#else
-          if constexpr (KLDS)
-            ef = eig_features<TRIG>(dxx, dxy, dxz, dyy, dyz, dzz, EigConstLds::at(ktab));
-          else
-            ef = eig_features<TRIG>(dxx, dxy, dxz, dyy, dyz, dzz);
-#endif
-          if constexpr (F8) {
-            o[0] = c; o[1] = G;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) o[2 + k] = ef.f[k];
-          } else {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) o[k] = ef.f[k];
-          }
-        }
-      }
+      feat_point<MODE, UNIT, TRIG, KLDS>(tile[(z - 1 - (z0 - 1)) & 3], tile[(z - (z0 - 1)) & 3],
+                                         tile[(z + 1 - (z0 - 1)) & 3], ty, tx, dc, ktab, o);
     }
     if (!keep) {
 #pragma unroll
@@ -472,6 +484,258 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES(MODE, UNIT, TRIG)) void fe
     }
   }
   flush();
+}
+
+// =====================================================================================
+// Ring form of the feature kernel: same tile, same arithmetic (feat_point), different plumbing.
+// =====================================================================================
+// For a single float field (the smoothed value S after the last axis pass, or a raw float
+// image) the staged planes need no arithmetic, so they go from memory straight into LDS
+// (`buffer_load_dword ... lds`): no staging registers, no ds_write, and -- because a plane in
+// flight costs LDS, not registers -- plane z+FR_P is requested while plane z is computed.  The
+// requests are counted by hand (the compiler does not see them): before the barrier of step z
+// a wave waits until at most the operations younger than ITS pieces of plane z+1 are
+// outstanding (vmcnt counts loads and stores together, in issue order), the barrier makes
+// every wave's pieces visible, and the output stores of the last FR_P-1 steps stay in flight
+// across it.  Round 2's kernel waited for vmcnt(0) in every step (a register it had spilled
+// came back through a scratch load behind the freshly issued prefetch), i.e. each wave sat
+// out the full memory latency once per plane.
+//
+// Every global access is a buffer access with a wave-uniform base in scalar registers and a
+// 32-bit per-lane offset that never changes (in-plane offsets, computed once); stores are
+// bounded by the descriptor's size instead of by EXEC (a row that ends inside the tile, a row
+// below the volume, a voxel that is not sampled: the hardware drops the access), so every
+// wave issues the same number of memory operations in every step, which is what makes the
+// counted waits exact.
+constexpr int FR_NS = 8;                   // ring slots (planes resident or in flight)
+#ifndef IFE_FR_P
+#define IFE_FR_P 4
+#endif
+constexpr int FR_P = IFE_FR_P;             // plane z+FR_P is requested in step z (FR_P + 2 <= FR_NS)
+constexpr int FR_VPIECES = (FT_NE + 63) / 64;   // 64-dword pieces of a staged plane (11)
+constexpr int FR_VDW = FR_VPIECES * 64;    // dwords of a slot reserved for the values
+constexpr int FR_MDW_MAX = FT_TY * FT_TX * 2 / 4;  // mask dwords of a slot (2-byte masks)
+constexpr int FR_SLOT_DW = FR_VDW + FR_MDW_MAX;
+static_assert(FR_P >= 2 && FR_P + 2 <= FR_NS, "ring too small for the prefetch distance");
+static_assert(FT_THREADS == 512 && FR_VPIECES <= 16, "piece assignment assumes eight waves, two pieces each at most");
+
+typedef uint32_t ft_u32x4 __attribute__((ext_vector_type(4)));
+// raw buffer descriptor (stride 0, byte range `bytes`) as four scalars for inline asm
+__device__ __forceinline__ ft_u32x4 ft_rsrc_words(const void *base, uint32_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  ft_u32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  r.y = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  r.w = 0x00020000u;
+  return r;
+}
+// One wave-instruction: lane l loads the dword at base + voff[l] into LDS dword lds_addr/4 + l.
+// M0 carries the LDS address; it is compiler-reserved, so it is saved and restored inside the
+// same statement.  Not counted by the compiler: see ft_wait_vmcnt.
+__device__ __forceinline__ void ft_dma_dword(ft_u32x4 rsrc, uint32_t voff, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dword %1, %2, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(lds_addr)
+      : "memory");
+}
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate is an instruction field)
+__device__ __forceinline__ void ft_wait_vmcnt(int n) {
+#define IFE_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    IFE_W(0) IFE_W(1) IFE_W(2) IFE_W(3) IFE_W(4) IFE_W(5) IFE_W(6) IFE_W(7) IFE_W(8) IFE_W(9)
+    IFE_W(10) IFE_W(11) IFE_W(12) IFE_W(13) IFE_W(14) IFE_W(15) IFE_W(16) IFE_W(17) IFE_W(18)
+    IFE_W(19) IFE_W(20) IFE_W(21) IFE_W(22) IFE_W(23) IFE_W(24) IFE_W(25) IFE_W(26) IFE_W(27)
+    IFE_W(28) IFE_W(29) IFE_W(30) IFE_W(31) IFE_W(32) IFE_W(33) IFE_W(34) IFE_W(35) IFE_W(36)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef IFE_W
+}
+__device__ __forceinline__ void ft_lds_barrier() {
+  // LDS only: global loads and stores in flight stay in flight across the barrier
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+#ifndef IFE_FT_NT_AUX
+#define IFE_FT_NT_AUX (IFE_FT_NT ? 2 : 0)
+#endif
+
+template <int MODE, bool UNIT, int TRIG, bool PLANAR, typename TM>
+__global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES(MODE, UNIT, TRIG)) void features_ring_kernel(
+    const float *__restrict__ val, const TM *__restrict__ mask, float *__restrict__ out, FeatGeom g,
+    DerivCoef dc) {
+  static_assert(sizeof(TM) <= 2, "mask tiles of wider types do not fit the slot");
+  using rsrc_t = __amdgpu_buffer_rsrc_t;
+  constexpr int NOUT = FeatNOut<MODE>::value;
+  constexpr bool F8 = MODE == FEAT_FEATURES8 || MODE == FEAT_SAMPLES8;
+  constexpr bool SAMPLES = MODE == FEAT_SAMPLES8;
+  static_assert(!SAMPLES || PLANAR, "sample columns are written through the planar store");
+  constexpr bool KLDS = (F8 || MODE == FEAT_EIG6) && IFE_FT_KLDS && TRIG != 2;
+  constexpr bool XPOSE = !PLANAR && (NOUT == 8 || NOUT == 6);
+  constexpr int XW = NOUT == 8 ? 4 : 2;       // floats per store of the interleaved form
+  constexpr int XN = XPOSE ? NOUT / XW : 1;   // stores per lane of the interleaved form
+  constexpr int NST = XPOSE ? XN : NOUT;      // stores every wave issues in every step
+  constexpr int MT_DW = FT_TY * FT_TX * (int)sizeof(TM) / 4;  // mask dwords per plane tile
+  constexpr int MT_DWROW = FT_TX * (int)sizeof(TM) / 4;       // mask dwords per tile row
+  constexpr int MPIECES = MT_DW / 64;
+
+  __shared__ __attribute__((aligned(16))) uint32_t ring[FR_NS * FR_SLOT_DW];
+  __shared__ float xstrip[XPOSE ? FT_THREADS / 64 : 1][XPOSE ? 64 * NOUT : 1];
+  __shared__ double ktab[KLDS ? EK_COUNT : 1];
+  if (KLDS) eig_const_fill(ktab);  // the barrier of the first step covers it
+
+  const int tid = threadIdx.x;
+  const int tx = tid & 63;
+  const int w = (int)__builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);  // wave = tile row
+  int bx, by, bz;
+  {  // XCD-aware tile order, as in features_kernel
+    const uint32_t nb = (uint32_t)g.gx * (uint32_t)g.gy * (uint32_t)g.gz;
+    const uint32_t lin = blockIdx.x;
+    const uint32_t per = nb / 8u, rem = nb % 8u;
+    const uint32_t c = lin % 8u, i = lin / 8u;
+    const uint32_t t = c * per + (c < rem ? c : rem) + i;
+    bx = (int)(t % (uint32_t)g.gx);
+    by = (int)((t / (uint32_t)g.gx) % (uint32_t)g.gy);
+    bz = (int)(t / ((uint32_t)g.gx * (uint32_t)g.gy));
+  }
+  const int x = bx * FT_TX + tx, y = by * FT_TY + w;
+  const int z0 = bz * g.zchunk;
+  const int z1 = min(z0 + g.zchunk, g.nz);
+  const bool has_mask = mask != nullptr;
+  const int row_valid = y < g.ny ? min(FT_TX, g.nx - bx * FT_TX) : 0;  // stored voxels of this wave's row
+
+  // ---- staging assignment: piece A = elements 64w.. of the halo tile; piece B = elements
+  // 512 + 64w.. (waves 0-2) or 64 dwords of the mask tile (the next MPIECES waves) ----
+  auto val_off = [&](int e) -> uint32_t {
+    if (e >= FT_NE) e = 0;  // the pad of the last piece repeats element 0 (never read)
+    const int ey = e / FT_HX, ex = e % FT_HX;
+    return 4u * ((uint32_t)clampi(bx * FT_TX - 1 + ex, g.nx - 1) +
+                 (uint32_t)g.nx * (uint32_t)clampi(by * FT_TY - 1 + ey, g.ny - 1));
+  };
+  const uint32_t offA = val_off(tid);
+  const bool b_val = w < FR_VPIECES - 8;
+  const bool b_mask = !b_val && has_mask && (w - (FR_VPIECES - 8)) < MPIECES;
+  const int n_dma = 1 + ((b_val || b_mask) ? 1 : 0);
+  uint32_t offB = 0;
+  if (b_val) {
+    offB = val_off(FT_THREADS + tid);
+  } else if (b_mask) {
+    const int d = (w - (FR_VPIECES - 8)) * 64 + tx;  // dword of the mask tile
+    int mx = bx * FT_TX + (d % MT_DWROW) * (4 / (int)sizeof(TM));
+    int my = by * FT_TY + d / MT_DWROW;
+    if (mx >= g.nx || my >= g.ny) { mx = bx * FT_TX; my = by * FT_TY; }  // any valid dword: never read
+    offB = (uint32_t)sizeof(TM) * ((uint32_t)mx + (uint32_t)g.nx * (uint32_t)my);
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)ring;
+  const uint32_t dstA = (uint32_t)w * 256u;
+  const uint32_t dstB = b_val ? (uint32_t)(8 + w) * 256u
+                              : (uint32_t)FR_VDW * 4u + (uint32_t)(w - (FR_VPIECES - 8)) * 256u;
+  auto slot_of = [&](int p) { return (uint32_t)(p - (z0 - 1)) & (uint32_t)(FR_NS - 1); };
+  auto request = [&](int p) {  // plane p of the values and of the mask into slot_of(p)
+    const uint32_t sb = lds0 + slot_of(p) * (uint32_t)(FR_SLOT_DW * 4);
+    const ft_u32x4 rv = ft_rsrc_words(val + (int64_t)clampi(p + g.zoff, g.zc_hi) * g.plane, 0xffffffffu);
+    ft_dma_dword(rv, offA, sb + dstA);
+    if (b_val) {
+      ft_dma_dword(rv, offB, sb + dstB);
+    } else if (b_mask) {
+      const ft_u32x4 rm = ft_rsrc_words(mask + (int64_t)clampi(p, g.nz - 1) * g.plane, 0xffffffffu);
+      ft_dma_dword(rm, offB, sb + dstB);
+    }
+  };
+
+  for (int p = z0 - 1; p <= min(z0 + FR_P - 1, z1); ++p) request(p);
+
+  for (int z = z0; z < z1; ++z) {
+    // this wave's pieces of plane z+1 have landed once at most the younger operations are
+    // outstanding: the requests for planes z+2 .. min(z+FR_P-1, z1) and the stores of the
+    // steps since that request was issued (step z+1-FR_P, or the prologue)
+    ft_wait_vmcnt(min(FR_P - 2, z1 - 1 - z) * n_dma + min(z - z0, FR_P - 1) * NST);
+    ft_lds_barrier();
+    if (z + FR_P <= z1) request(z + FR_P);
+
+    const float(*tm)[FT_HX] = reinterpret_cast<const float(*)[FT_HX]>(ring + slot_of(z - 1) * FR_SLOT_DW);
+    const float(*t0)[FT_HX] = reinterpret_cast<const float(*)[FT_HX]>(ring + slot_of(z) * FR_SLOT_DW);
+    const float(*tp)[FT_HX] = reinterpret_cast<const float(*)[FT_HX]>(ring + slot_of(z + 1) * FR_SLOT_DW);
+    bool keep = x < g.nx && row_valid > 0;
+    bool samp = false;
+    if (has_mask) {
+      const TM mval = reinterpret_cast<const TM *>(ring + slot_of(z) * FR_SLOT_DW + FR_VDW)[tid];
+      if constexpr (SAMPLES) {
+        samp = keep && ((int)mval & 1) != 0;
+        keep = keep && ((int)mval & 3) == 3;
+      } else {
+        keep = keep && mval != (TM)0;
+      }
+    } else if constexpr (SAMPLES) {
+      samp = keep;
+    }
+    float o[NOUT];
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) o[k] = 0.0f;
+    // a wave whose voxels are all outside the mask skips the arithmetic (scalar branch)
+    if (__builtin_amdgcn_ballot_w64(keep) != 0) feat_point<MODE, UNIT, TRIG, KLDS>(tm, t0, tp, w, tx, dc, ktab, o);
+    if (!keep) {
+#pragma unroll
+      for (int k = 0; k < NOUT; ++k) o[k] = 0.0f;
+    }
+    // ---- stores: bounded by the descriptor, issued by every wave in every step ----
+    const int64_t row0 = (int64_t)bx * FT_TX + (int64_t)g.nx * ((int64_t)y + (int64_t)g.ny * z);
+    if constexpr (XPOSE) {
+      // the 64 records of the row are one contiguous run: turned through a wave-private LDS
+      // strip so that store k of lane l carries piece k*64 + l of it
+      float *xs = xstrip[w];
+      if constexpr (XW == 4) {
+        *reinterpret_cast<float4 *>(xs + tx * 8) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4 *>(xs + tx * 8 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < XN; ++k)
+          *reinterpret_cast<float2 *>(xs + tx * NOUT + 2 * k) = make_float2(o[2 * k], o[2 * k + 1]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + row0 * NOUT, 0, row_valid * NOUT * 4, 0x00020000);
+#pragma unroll
+      for (int k = 0; k < XN; ++k) {
+        if constexpr (XW == 4) {
+          const ft_u32x4 v = *reinterpret_cast<const ft_u32x4 *>(xs + (k * 64 + tx) * 4);
+          __builtin_amdgcn_raw_buffer_store_b128(v, ro, (uint32_t)(k * 64 + tx) * 16u, 0, IFE_FT_NT_AUX);
+        } else {
+          typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 v = *reinterpret_cast<const u32x2 *>(xs + (k * 64 + tx) * 2);
+          __builtin_amdgcn_raw_buffer_store_b64(v, ro, (uint32_t)(k * 64 + tx) * 8u, 0, IFE_FT_NT_AUX);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // the strip is written again in the next step
+    } else if constexpr (SAMPLES) {
+      // eight sample columns; the sampled voxels of this row segment go to consecutive slots
+      const uint64_t sm = __builtin_amdgcn_ballot_w64(samp);
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
+      const int64_t seg = (int64_t)bx + (int64_t)g.gx * ((int64_t)y + (int64_t)g.ny * z);
+      int64_t first = 0;
+      if (sm != 0) first = g.col_offset + (int64_t)g.seg_base[seg];  // uniform: a scalar load
+      const uint32_t voff = samp ? rank * 4u : 0x7ffffff0u;
+      const int cnt = __builtin_popcountll(sm);
+#pragma unroll
+      for (int k = 0; k < NOUT; ++k) {
+        const rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)k * g.nvox + first, 0, cnt * 4, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o[k]), ro, voff, 0, IFE_FT_NT_AUX);
+      }
+    } else {
+      // planar components (or the single output of FEAT_GRADMAG): 64 consecutive floats per store
+#pragma unroll
+      for (int k = 0; k < NOUT; ++k) {
+        const rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)k * g.nvox + row0, 0, row_valid * 4, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o[k]), ro, (uint32_t)tx * 4u, 0, IFE_FT_NT_AUX);
+      }
+    }
+  }
 }
 
 // ---- per-voxel numerics on a flat batch (a1 / a2 parity hooks) -----------------------

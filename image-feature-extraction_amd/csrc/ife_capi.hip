@@ -88,6 +88,7 @@ struct ife_ctx {
   int iir_ckpt = 2;  // register blocks per checkpoint of the strided line kernel: 1 or 2
   int fused_divide = 1;  // last axis pass stores numerator / denominator (sibling waves), not two fields
   int const_lines = 1;   // lines of one repeated 0 or 1 are copied, not filtered, where verified exact
+  int feat_ring = 1;     // feature kernel: planes by LDS-DMA into a ring where the source is one float field
   std::map<std::tuple<double, double, int64_t>, uint32_t> const_flags;  // (sigma, spacing, length) -> IirJob::const_lines
   // per scale slot: numerator ping/pong, denominator ping/pong (up to three scales run
   // through the line kernels together)
@@ -759,9 +760,32 @@ int launch_features(ife_ctx *ctx, VAL val, const TM *mask, float *out,
   const bool unit = v->sx == 1.0 && v->sy == 1.0 && v->sz == 1.0;
   const int planar = layout == IFE_PLANAR ? 1 : 0;
   constexpr bool has_eig = MODE == FEAT_FEATURES8 || MODE == FEAT_EIG6 || MODE == FEAT_SAMPLES8;
+  // ring form (feature_kernels.hpp): one float field, narrow mask, dword-aligned mask planes,
+  // in-plane byte offsets that fit 32 bits
+  constexpr bool ring_types = (std::is_same<VAL, ValS>::value || std::is_same<VAL, ValRaw<float>>::value) &&
+                              sizeof(TM) <= 2;
+  bool ring = false;
+  const float *ring_src = nullptr;
+  if constexpr (ring_types) {
+    if constexpr (std::is_same<VAL, ValS>::value) ring_src = val.s;
+    else ring_src = val.img;
+    const int64_t row_bytes = v->nx * (int64_t)sizeof(TM), plane_bytes = g.plane * (int64_t)sizeof(TM);
+    ring = ctx->feat_ring && g.plane < ((int64_t)1 << 30) && reinterpret_cast<uintptr_t>(ring_src) % 4 == 0 &&
+           (mask == nullptr ||
+            (row_bytes % 4 == 0 && plane_bytes % 4 == 0 && reinterpret_cast<uintptr_t>(mask) % 4 == 0));
+  }
 #define IFE_LAUNCH_FEAT2(UNIT_, TRIG_, PL_)                                                    \
-  hipLaunchKernelGGL((features_kernel<MODE, UNIT_, TRIG_, PL_, VAL, TM>), grid,                 \
-                     dim3(FT_THREADS), 0, ctx->stream, val, mask, out, g, dc)
+  do {                                                                                         \
+    if constexpr (ring_types) {                                                                \
+      if (ring) {                                                                              \
+        hipLaunchKernelGGL((features_ring_kernel<MODE, UNIT_, TRIG_, PL_, TM>), grid,          \
+                           dim3(FT_THREADS), 0, ctx->stream, ring_src, mask, out, g, dc);      \
+        break;                                                                                 \
+      }                                                                                        \
+    }                                                                                          \
+    hipLaunchKernelGGL((features_kernel<MODE, UNIT_, TRIG_, PL_, VAL, TM>), grid,              \
+                       dim3(FT_THREADS), 0, ctx->stream, val, mask, out, g, dc);               \
+  } while (0)
 #define IFE_LAUNCH_FEAT(UNIT_, TRIG_)                                                  \
   do {                                                                                 \
     if constexpr (MODE == FEAT_SAMPLES8) IFE_LAUNCH_FEAT2(UNIT_, TRIG_, true);         \
@@ -986,6 +1010,9 @@ int ife_ctx_set_option(ife_ctx *ctx, int option, int value) {
       return IFE_OK;
     case IFE_OPT_FUSED_DIVIDE:
       ctx->fused_divide = value ? 1 : 0;
+      return IFE_OK;
+    case IFE_OPT_FEAT_RING:
+      ctx->feat_ring = value ? 1 : 0;
       return IFE_OK;
     case IFE_OPT_IIR_BLOCK:
       if (value != 0 && value != 8 && value != 10 && value != 12 && value != 16)

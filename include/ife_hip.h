@@ -99,7 +99,13 @@ typedef enum {
    * through the kernels' arithmetic (decided per wave of 64 adjacent lines): the exterior of a
    * mask costs a read and a write.  Same results bit for bit, signs of zero included; 0:
    * every line is filtered. */
-  IFE_OPT_CONST_LINES = 9
+  IFE_OPT_CONST_LINES = 9,
+  /* 1 (default): where the feature kernel reads ONE float field (the smoothed value after a
+   * quotient-storing last pass, or a raw float image) and the mask is 1 or 2 bytes wide, its
+   * planes go from memory straight into an LDS ring several planes ahead of the arithmetic
+   * (no staging registers, counted waits); 0: the register-staged form everywhere.  Same
+   * arithmetic function, same results bit for bit. */
+  IFE_OPT_FEAT_RING = 10
 } ife_option;
 
 typedef struct {
