@@ -289,8 +289,6 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES(MODE, UNIT, TRIG)) void fe
   __shared__ double ktab[KLDS ? EK_COUNT : 1];
   if (KLDS) eig_const_fill(ktab);  // the barrier of the first plane iteration covers it
   constexpr int NOUT = FeatNOut<MODE>::value;
-  constexpr bool NEED_H = MODE != FEAT_GRADMAG;
-  constexpr bool NEED_G = F8 || MODE == FEAT_GRADMAG;
 
   const int tid = threadIdx.x;
   const int tx = tid & 63, ty = tid >> 6;
