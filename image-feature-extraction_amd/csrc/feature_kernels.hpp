@@ -521,10 +521,10 @@ typedef uint32_t ft_u32x4 __attribute__((ext_vector_type(4)));
 // raw buffer descriptor (stride 0, byte range `bytes`) as four scalars for inline asm
 __device__ __forceinline__ ft_u32x4 ft_rsrc_words(const void *base, uint32_t bytes) {
   const uint64_t a = reinterpret_cast<uint64_t>(base);
-  ft_u32x4 r;
-  r.x = __builtin_amdgcn_readfirstlane((uint32_t)a);
-  r.y = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
-  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  ft_u32x4 r;  // all four words wave-uniform: the asm's "s" constraint refuses anything else
+  r.x = (uint32_t)a;
+  r.y = (uint32_t)(a >> 32) & 0xffffu;
+  r.z = bytes;
   r.w = 0x00020000u;
   return r;
 }
@@ -652,7 +652,12 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES(MODE, UNIT, TRIG)) void fe
     // this wave's pieces of plane z+1 have landed once at most the younger operations are
     // outstanding: the requests for planes z+2 .. min(z+FR_P-1, z1) and the stores of the
     // steps since that request was issued (step z+1-FR_P, or the prologue)
-    ft_wait_vmcnt(min(FR_P - 2, z1 - 1 - z) * n_dma + min(z - z0, FR_P - 1) * NST);
+    if (z - z0 >= FR_P - 1 && z1 - 1 - z >= FR_P - 2) {  // steady state: one compare pair, no table
+      if (n_dma == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FR_P - 2) * 2 + (FR_P - 1) * NST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FR_P - 2) * 1 + (FR_P - 1) * NST) : "memory");
+    } else {
+      ft_wait_vmcnt(min(FR_P - 2, z1 - 1 - z) * n_dma + min(z - z0, FR_P - 1) * NST);
+    }
     ft_lds_barrier();
     if (z + FR_P <= z1) request(z + FR_P);
 
@@ -673,11 +678,16 @@ __global__ __launch_bounds__(FT_THREADS, IFE_FT_WAVES(MODE, UNIT, TRIG)) void fe
       samp = keep;
     }
     float o[NOUT];
+    // a wave whose voxels are all outside the mask skips the arithmetic, one whose voxels are
+    // all inside skips the masking (scalar branches; the interior of a mask pays neither)
+    const uint64_t kept = __builtin_amdgcn_ballot_w64(keep);
+    if (kept != 0) {
+      feat_point<MODE, UNIT, TRIG, KLDS>(tm, t0, tp, w, tx, dc, ktab, o);
+      if (kept != __builtin_amdgcn_ballot_w64(true)) {
 #pragma unroll
-    for (int k = 0; k < NOUT; ++k) o[k] = 0.0f;
-    // a wave whose voxels are all outside the mask skips the arithmetic (scalar branch)
-    if (__builtin_amdgcn_ballot_w64(keep) != 0) feat_point<MODE, UNIT, TRIG, KLDS>(tm, t0, tp, w, tx, dc, ktab, o);
-    if (!keep) {
+        for (int k = 0; k < NOUT; ++k) o[k] = keep ? o[k] : 0.0f;
+      }
+    } else {
 #pragma unroll
       for (int k = 0; k < NOUT; ++k) o[k] = 0.0f;
     }
