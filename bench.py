@@ -26,6 +26,9 @@ import time
 
 import numpy as np
 
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALG_BYTES_PER_VOXEL_SCALE = 37  # SURVEY.md section 8d: 4 (image) + 1 (mask) + 8*4 (out)
+
 # N > 1: a rank drives nine streams (bulk, boundary chain, receive posting, and RCCL's own
 # stream per edge and traffic class).  HIP multiplexes streams onto GPU_MAX_HW_QUEUES
 # hardware queues (default 4), and a receive kernel that spins for its neighbour would hold
@@ -40,19 +43,36 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 PKG = "image-feature-extraction_amd"
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-ALG_BYTES_PER_VOXEL_SCALE = 37  # SURVEY.md section 8d: 4 (image) + 1 (mask) + 8*4 (out)
-# compulsory bytes per voxel of ONE field pass / feature launch of each kernel kind
-# (DESIGN.md "Kernels"): a line-kernel launch covers several (scale, field) jobs
-KERNEL_ALG_BYTES = {"iir_z": 8.0, "iir_x": 8.0, "iir_y": 8.0, "features": 41.0, "prep": 13.0,
+# compulsory bytes per voxel of ONE field pass / feature launch of each kernel kind (DESIGN.md
+# "Kernels"): a line-kernel launch covers several (scale, field) jobs.  Two entries depend on
+# the options of the run (kernel_alg_bytes): with the quotient stored by the last axis pass
+# (the default with a mask) that pass writes half a value per field and the feature kernel
+# reads one field, 4 + 1 + 32 = 37 B; with two fields out of the last pass it reads both, 41 B.
+KERNEL_ALG_BYTES = {"iir_z": 8.0, "iir_x": 8.0, "iir_y": 8.0, "features": 37.0, "prep": 13.0,
                     "zslab_sweep": 4.0, "zslab_combine": 8.0}
-# Second roofline (DESIGN.md "Where the time goes"): vector instructions a wave issues per
-# 64 samples of one field pass / per 64 voxels of a feature launch, from the committed PMC
-# pass (profiles/r02_pmc_summary.txt: SQ_INSTS_VALU / waves' samples).  On CDNA4 a double
-# add / multiply occupies its SIMD for 4 cycles per wave, so
-#   issue_floor_ms = instructions x 4 / (256 CUs x 4 SIMDs x sustained clock).
-VALU_PER_WAVE64 = {"iir_z": 55.5, "iir_x": 57.2, "iir_y": 59.5, "features": 240.0}
+
+
+def kernel_alg_bytes(args):
+    k = dict(KERNEL_ALG_BYTES)
+    masked = args.mask != "none"
+    fused = masked and not args.no_fused_divide and (args.iir_ckpt or 2) == 2
+    if masked and fused:
+        k["iir_y"] = 6.0       # 4 in, the quotient shared by the two fields out
+    elif masked:
+        k["features"] = 41.0   # numerator and denominator in
+    if not masked:
+        k["features"] = 36.0   # no mask byte
+    return k
+
+
+# Second roofline (DESIGN.md "Where the time goes"): on CDNA4 a vector instruction of a wave64
+# occupies its SIMD's issue for 4 cycles, so a kernel cannot finish before
+#   instructions x 4 / (256 CUs x 4 SIMDs x sustained clock).
+# The instruction counts are SQ_INSTS_VALU per launch from the committed PMC passes of this
+# workload (profiles/r03_traffic.json, written by scripts/make_traffic.py), read by kernel kind.
 SIMDS, SUSTAINED_GHZ = 1024, 2.03  # GRBM_GUI_ACTIVE / 8 / duration under this load
+PROFILE_JSON = "r03_traffic.json"
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -87,6 +107,8 @@ def parse():
     ap.add_argument("--feat-ring", type=int, default=1, choices=[0, 1],
                     help="IFE_OPT_FEAT_RING (A/B): 1 planes by LDS-DMA into a ring (default), 0 register-staged")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stream-probe", action="store_true",
+                    help="skip the 4-GiB fill / copy that measures the box's streaming rates")
     ap.add_argument("--force-slab", action="store_true",
                     help="run the Z-slab engine (RCCL exchanges) even with one rank")
     ap.add_argument("--cpu-sample", type=int, default=512, help="edge of the CPU baseline cube")
@@ -212,19 +234,17 @@ def cpu_baseline(synth, seed, sigmas, edge):
                       "%.1f s of CPU work" % (edge, list(sigmas), dt)}
 
 
-def measured_copy_gbs(torch, dev, nbytes=1 << 30, reps=5):
-    """Device-to-device copy rate (bytes read + bytes written per second): the achievable
-    HBM ceiling on this box, printed beside the 8 TB/s peak."""
-    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).fill_(1.0)
-    b = torch.empty_like(a)
-    b.copy_(a)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        b.copy_(a)
-    e1.record()
-    torch.cuda.synchronize()
-    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+def measured_stream_gbs(torch, ctx, dev, nbytes=4 << 30, reps=5):
+    """The box's own streaming rates with this library's access shape (16 B per lane,
+    non-temporal, grid-stride; ife_measure_stream): a 4-GiB fill (bytes written per second) and
+    a 4-GiB copy (bytes read + written per second).  Printed beside the 8 TB/s peak as what a
+    pure stream achieves here; far larger than the 256 MB Infinity Cache."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    b = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    fill = ctx.measure_stream(0, a.data_ptr(), None, nbytes, reps)
+    copy = ctx.measure_stream(1, b.data_ptr(), a.data_ptr(), nbytes, reps)
+    del a, b
+    return fill, copy
 
 
 def main():
@@ -294,7 +314,6 @@ def main():
             n0, ms0 = ktimes.get(name, (0, 0.0))
             ktimes[name] = (n0 + n, ms0 + ms)
         c.set_option(pkg.OPT_PROFILE, 0)
-    copy_gbs = measured_copy_gbs(torch, dev) if rank == 0 else None
     # beside the headline: the same step with the library's default constant-line shortcut
     shortcut_ms = None
     if not use_dist and not args.const_lines and not args.no_shortcut_leg:
@@ -307,6 +326,10 @@ def main():
         torch.cuda.synchronize()
         shortcut_ms = (time.perf_counter() - t1) / 3 * 1e3
         runner.ctx.set_option(pkg.OPT_CONST_LINES, 0)
+    fill_gbs = copy_gbs = None
+    if rank == 0 and not use_dist and not args.no_stream_probe:
+        runner.release_outputs()  # the output volumes go back to the allocator before the probe's 8 GiB
+        fill_gbs, copy_gbs = measured_stream_gbs(torch, runner.ctx, dev)
 
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -318,27 +341,38 @@ def main():
     value = nvox * len(sigmas) / t_step / 1e6
 
     # ---- roofline: whole hot path, per step, from HIP events around every kernel ----
+    # HBM bytes and vector instructions per launch come from the committed PMC passes of the
+    # DEFAULT workload (PMC counters cannot be collected from inside this process)
+    default_cfg = (not use_dist and [nz, ny, nx] == [512, 512, 512] and sigmas == [1.0, 2.0, 4.0]
+                   and args.mask == "ones" and args.layout == "interleaved" and args.trig == 2
+                   and not args.i16 and list(args.spacing) == [1.0, 1.0, 1.0] and not args.iir_fma
+                   and not args.iir_block and not args.no_fused_divide and args.feat_ring == 1)
+    tpath = os.path.join(ROOT, "profiles", PROFILE_JSON)
+    prof = json.load(open(tpath)) if default_cfg and os.path.exists(tpath) else None
+    prof_kinds = (prof or {}).get("kinds", {})
+    alg = kernel_alg_bytes(args)
     kern = {}
     dev_ms_step = 0.0
+    issue_floor_step = 0.0
     nfields = 1 if args.mask == "none" else 2
     for name, (n, ms) in ktimes.items():
         per_step_ms = ms / args.steps
         dev_ms_step += per_step_ms
         e = {"launches_per_step": n / args.steps, "avg_ms": round(ms / n, 4),
              "ms_per_step": round(per_step_ms, 4)}
-        if name in KERNEL_ALG_BYTES:
+        if name in alg:
             # units of work per step: field passes for the line kernels, scales for the rest
             units = {"prep": 1, "features": len(sigmas)}.get(name, len(sigmas) * nfields)
-            gbs = KERNEL_ALG_BYTES[name] * units * (nvox / world) / (per_step_ms * 1e-3) / 1e9
-            e["alg_bytes_per_voxel"] = KERNEL_ALG_BYTES[name]
+            gbs = alg[name] * units * (nvox / world) / (per_step_ms * 1e-3) / 1e9
+            e["alg_bytes_per_voxel"] = alg[name]
             e["units_per_step"] = units
             e["achieved_GBs"] = round(gbs, 1)
             e["frac"] = round(gbs / HBM_PEAK_GBS, 4)
-        if name in VALU_PER_WAVE64:
-            units = len(sigmas) if name == "features" else len(sigmas) * nfields
-            insts = VALU_PER_WAVE64[name] * units * (nvox / world) / 64.0
-            e["issue_floor_ms"] = round(insts * 4.0 / (SIMDS * SUSTAINED_GHZ * 1e9) * 1e3
-                                        / (n / args.steps), 4)  # per launch, like avg_ms
+        if name in prof_kinds and prof_kinds[name].get("valu_insts"):
+            floor = prof_kinds[name]["valu_insts"] * 4.0 / (SIMDS * SUSTAINED_GHZ * 1e9) * 1e3
+            e["valu_insts_per_launch"] = prof_kinds[name]["valu_insts"]
+            e["issue_floor_ms"] = round(floor, 4)  # per launch, like avg_ms
+            issue_floor_step += floor * n / args.steps
         kern[name] = e
     alg_bytes_step_rank = ALG_BYTES_PER_VOXEL_SCALE * (nvox / world) * len(sigmas)
     # one GPU: the kernels of a step run back to back, their hipEvent durations add up to the
@@ -347,21 +381,25 @@ def main():
     scope_ms = t_step * 1e3 if use_dist else dev_ms_step
     achieved = alg_bytes_step_rank / (scope_ms * 1e-3) / 1e9 if scope_ms > 0 else 0.0
     dominant = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
-    # HBM bytes per step from the committed PMC passes (profiles/, same default workload);
-    # PMC counters cannot be collected from inside this process
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    default_cfg = (not use_dist and [nz, ny, nx] == [512, 512, 512] and sigmas == [1.0, 2.0, 4.0]
-                   and args.mask == "ones" and args.layout == "interleaved" and args.trig == 2
-                   and not args.i16 and list(args.spacing) == [1.0, 1.0, 1.0])
-    if default_cfg and os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("traffic_bytes_per_step")
+    traffic = prof.get("traffic_bytes_per_step") if prof else None
+    issue = None
+    if prof and issue_floor_step > 0:
+        issue = {"floor_ms_per_step": round(issue_floor_step, 3),
+                 "frac_of_issue_roofline": round(issue_floor_step / dev_ms_step, 4),
+                 "rule": "SQ_INSTS_VALU per launch x 4 cycles / (%d SIMDs x %.2f GHz), summed over the "
+                         "launches of a step; measured: the sum of hipEvent durations" % (SIMDS, SUSTAINED_GHZ),
+                 "source": "profiles/%s (rocprofv3 PMC, SQ_INSTS_VALU per launch and kernel)" % PROFILE_JSON}
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_step": int(alg_bytes_step_rank),
+                "measured_fill_GBs": round(fill_gbs, 1) if fill_gbs else None,
                 "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
-                "traffic_source": "profiles/r02_traffic.json (rocprofv3 PMC, bytes per step)"
+                "measured_stream_note": "4-GiB float4 fill (bytes written / s) and copy (bytes read + written / s) "
+                                        "with this library's access shape, on this box, after the timed region"
+                if fill_gbs else None,
+                "traffic_source": "profiles/%s (rocprofv3 PMC, bytes per step)" % PROFILE_JSON
                 if traffic else None,
+                "issue": issue,
                 "scope": ("this rank's share of one step over the step's wall time (%.3f ms; the kernels "
                           "of its two streams overlap: their hipEvent durations sum to %.3f ms); "
                           % (scope_ms, dev_ms_step) if use_dist else
@@ -443,6 +481,9 @@ class SingleGpuRunner:
 
     def contexts(self):
         return [self.ctx]
+
+    def release_outputs(self):
+        self.d_out = None
 
     def step(self):
         self.ctx.emphysema_features_device(

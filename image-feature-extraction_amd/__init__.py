@@ -44,7 +44,7 @@ EXPORTS = (
     "ife_emphysema_features",
     "ife_emphysema_features_begin", "ife_emphysema_features_fetch", "ife_emphysema_features_end",
     "ife_fd_hessian_features", "ife_fd_gradient_features", "ife_mask_image_f64",
-    "ife_get_kernel_times", "ife_reset_kernel_times",
+    "ife_get_kernel_times", "ife_reset_kernel_times", "ife_measure_stream",
     "ife_stage_prepare", "ife_stage_recursive_gaussian", "ife_stage_recursive_gaussian_batch",
     "ife_stage_features", "ife_stage_z_ck_bytes", "ife_stage_z_sweep", "ife_stage_z_combine",
     "ife_multi_create", "ife_multi_destroy", "ife_multi_last_error", "ife_multi_set_option",
@@ -138,6 +138,7 @@ def load_library():
     lib.ife_multi_emphysema_features.argtypes = [vp, vp, i32, vp, i32, vd, C.POINTER(C.c_float), i32, f32p, i32]
     lib.ife_get_kernel_times.argtypes = [vp, C.POINTER(KernelTime), i32]
     lib.ife_reset_kernel_times.argtypes = [vp]
+    lib.ife_measure_stream.argtypes = [vp, i32, vp, vp, C.c_size_t, i32, C.POINTER(C.c_double)]
     lib.ife_sort_f32.argtypes = [vp, vp, i64, vp, i32]
     lib.ife_equalized_edges_f32.argtypes = [vp, vp, i64, i32, vp, i32]
     lib.ife_equalized_edges_f64.argtypes = [vp, vp, i64, i32, vp, i32]
@@ -223,6 +224,15 @@ class Context:
         n = self._chk(self._lib.ife_get_kernel_times(self._h, arr, 16))
         return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms))
                 for i in range(n)}
+
+    def measure_stream(self, mode, dst_ptr, src_ptr, nbytes, reps=5):
+        """GB/s of a 16-byte-per-lane fill (mode 0: bytes written) or copy (mode 1: bytes read +
+        written) over device buffers (ife_measure_stream)."""
+        ms = C.c_double()
+        self._chk(self._lib.ife_measure_stream(self._h, int(mode), C.c_void_p(dst_ptr),
+                                               C.c_void_p(src_ptr or 0), C.c_size_t(nbytes),
+                                               int(reps), C.byref(ms)))
+        return (1 if mode == 0 else 2) * nbytes / (ms.value * 1e-3) / 1e9
 
     def reset_kernel_times(self):
         self._chk(self._lib.ife_reset_kernel_times(self._h))

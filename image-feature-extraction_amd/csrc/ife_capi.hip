@@ -1498,6 +1498,53 @@ int ife_get_kernel_times(ife_ctx *ctx, ife_kernel_time *entries, int max_entries
   return k;
 }
 
+// The box's own streaming rates, measured with this library's access shape (16 B per lane,
+// grid-stride, hipEvents on the context's stream): what the roofline fractions in bench.py are
+// read against beside the 8 TB/s peak.
+__global__ __launch_bounds__(256) void stream_fill_kernel(float4 *__restrict__ dst, int64_t n4, float v) {
+  const float4 x = make_float4(v, v, v, v);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+    __builtin_nontemporal_store(f32x4{x.x, x.y, x.z, x.w}, reinterpret_cast<f32x4 *>(dst) + i);
+}
+__global__ __launch_bounds__(256) void stream_copy_kernel(const float4 *__restrict__ src,
+                                                          float4 *__restrict__ dst, int64_t n4) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+    __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src) + i),
+                                reinterpret_cast<f32x4 *>(dst) + i);
+}
+int ife_measure_stream(ife_ctx *ctx, int mode, void *dst, const void *src, size_t bytes, int reps,
+                       double *ms_per_pass) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if (!dst || !ms_per_pass || (mode == 1 && !src) || (mode != 0 && mode != 1) || reps < 1)
+    return fail(ctx, IFE_E_ARG, "bad arguments");
+  if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 || bytes % 16 || bytes == 0)
+    return fail(ctx, IFE_E_ARG, "buffers and size must be multiples of 16 bytes");
+  const int64_t n4 = (int64_t)(bytes / 16);
+  const unsigned blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, 256 * 32);
+  hipEvent_t a, b;
+  IFE_HIP(ctx, hipEventCreate(&a));
+  IFE_HIP(ctx, hipEventCreate(&b));
+  auto launch = [&]() {
+    if (mode == 0) hipLaunchKernelGGL(stream_fill_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (float4 *)dst, n4, 1.0f);
+    else hipLaunchKernelGGL(stream_copy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const float4 *)src, (float4 *)dst, n4);
+  };
+  launch();  // warm
+  (void)hipEventRecord(a, ctx->stream);
+  for (int i = 0; i < reps; ++i) launch();
+  (void)hipEventRecord(b, ctx->stream);
+  hipError_t e = hipEventSynchronize(b);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  if (e != hipSuccess) return fail(ctx, IFE_E_HIP, "stream measurement: %s", hipGetErrorString(e));
+  *ms_per_pass = (double)ms / reps;
+  return IFE_OK;
+}
+
 int ife_reset_kernel_times(ife_ctx *ctx) {
   int rc = bind(ctx);
   if (rc) return rc;

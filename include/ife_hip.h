@@ -429,6 +429,12 @@ typedef struct {
  * written (<= max_entries) or a negative status. */
 int ife_get_kernel_times(ife_ctx *ctx, ife_kernel_time *entries, int max_entries);
 int ife_reset_kernel_times(ife_ctx *ctx);
+/* The box's streaming rate with 16-byte accesses per lane (no reference counterpart; bench.py
+ * prints it beside the 8 TB/s peak): mode 0 writes `bytes` to dst (a fill), mode 1 copies
+ * `bytes` from src to dst; DEVICE pointers, 16-byte aligned.  One warm pass, then `reps`
+ * timed passes between hipEvents on the context's stream; *ms_per_pass is their average. */
+int ife_measure_stream(ife_ctx *ctx, int mode, void *dst, const void *src, size_t bytes, int reps,
+                       double *ms_per_pass);
 
 #ifdef __cplusplus
 }

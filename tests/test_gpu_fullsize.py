@@ -93,12 +93,18 @@ def test_bench_workload_matches_oracle_at_full_size(ife, oracle, big, dev):
             got = dev["out_a"].cpu().numpy()
             assert np.array_equal(got[..., 0], ref[..., 0]), "smoothed value, sigma %g" % sigma
             assert np.array_equal(got[..., 1], ref[..., 1]), "gradient magnitude, sigma %g" % sigma
-            p = assert_eig_parity(got, ref, tol, "sigma %g mode %d" % (sigma, mode))
+            # measured in round 2: 3-6 of 134 M triples per scale in the default mode, 0 in mode 0
+            p = assert_eig_parity(got, ref, tol, "sigma %g mode %d" % (sigma, mode),
+                                  max_order=16 if mode == 2 else 0)
             print("512^3 all-ones sigma %g trig mode %d: max eigenvalue error %.3g |lambda1| "
                   "(sum %.3g, Frobenius %.3g, product %.3g |lambda1|^3), %d of %d triples in "
-                  "another order, magnitude-order slack %.3g"
+                  "another order (%d magnitude ties within %.0e in the reference; worst "
+                  "element-wise error there %.3g |lambda1|, %d with opposite signs, widest "
+                  "swapped pair %.3g |lambda1| apart), magnitude-order slack %.3g"
                   % (sigma, mode, p["max_err"], p["max_err_sum"], p["max_err_frob"],
-                     p["max_err_prod"], p["order_diff"], p["n"], p["mag_slack"]))
+                     p["max_err_prod"], p["order_diff"], p["n"], p["near_ties"], 2 * tol,
+                     p["order_max_elem_err"], p["order_opposite_sign"], p["order_max_tie_gap"],
+                     p["mag_slack"]))
             del got
         del ref
     del d_ones
