@@ -83,7 +83,7 @@ struct ife_ctx {
   int dscale_mode = 0;
   int profile = 0;
   int zchunk = 64;
-  int iir_block = 0;   // 0: per axis (z 10 -- four waves per SIMD --, y 12, x 16); else 8 | 10 | 12 | 16
+  int iir_block = 0;   // 0: per axis (z 12, y 12, x 16); else 8 | 10 | 12 | 16
   int iir_fma = 0;   // 1: fused multiply-add in the line recurrences (opt-in, not bit-exact)
   int iir_ckpt = 2;  // register blocks per checkpoint of the strided line kernel: 1 or 2
   int fused_divide = 1;  // last axis pass stores numerator / denominator (sibling waves), not two fields
@@ -529,10 +529,11 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
   g.ngroups = (int32_t)((g.nlines + (in2 ? 127 : 255)) / (in2 ? 128 : 256));  // paired: 128 lines x 2 fields
   const dim3 grid((unsigned)((g.ngroups + 7) / 8 * 8 * njobs), 1, 1);  // job-fastest, padded
   ProfScope ps(ctx, axis == 2 ? KK_IIR_Z : axis == 1 ? KK_IIR_Y : KK_IIR_X);
-  // register block of the strided axes: z is bound by issue and gains from a fourth wave per
-  // SIMD (blocks of 10: 109 VGPRs, 40 KB of parked values per workgroup); y is bound by HBM and
-  // prefers the fewer checkpoints of 12 (measured: z 1.82 -> 1.74 ms, y 1.98 -> 2.12 with 10)
-  const int sblock = ctx->iir_block ? ctx->iir_block : (axis == 2 ? 10 : 12);
+  // register block of the strided axes: 12 for both (three waves per SIMD, 2.7 B of checkpoints
+  // per sample).  Round 2 ran z with blocks of 10 for a fourth wave per SIMD; since the waits
+  // are exact (iir_kernels.inc "Memory operations and waits") three waves hide the latency and
+  // the fewer checkpoints win: z 1.85 -> 1.74 ms, y 1.87 with 12 against 2.06 with 16.
+  const int sblock = ctx->iir_block ? ctx->iir_block : 12;
 #define IFE_LAUNCH_IIR(NS)                                                                      \
   do {                                                                                          \
     if (axis == 0) {                                                                            \
@@ -656,7 +657,10 @@ int launch_prep(ife_ctx *ctx, const TI *img, const TM *msk, float *tc, float *cf
   const bool vec = al == 0 && (pg.chunks <= 1 || pg.nx % 4 == 0);
   const int64_t n4 = vec ? n / 4 : 0;
   if (n4 > 0) {
-    const unsigned blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, 8192);
+    // one 16-byte piece per thread (the kernel's loop runs once): on MI355X a stream moves
+    // faster as many short-lived workgroups than as a grid-stride loop of a few thousand
+    // (scripts/experiments/stream_probe.hip: fill 6.9 vs 5.0 TB/s, copy 6.4 vs 4.9)
+    const unsigned blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, 0x7fffffff);
     hipLaunchKernelGGL((prep_kernel_vec4<TI, TM>), dim3(blocks), dim3(256), 0, ctx->stream, img,
                        msk, tc, cf, n4, pg);
     IFE_HIP(ctx, hipGetLastError());
@@ -1523,7 +1527,8 @@ int ife_measure_stream(ife_ctx *ctx, int mode, void *dst, const void *src, size_
   if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 || bytes % 16 || bytes == 0)
     return fail(ctx, IFE_E_ARG, "buffers and size must be multiples of 16 bytes");
   const int64_t n4 = (int64_t)(bytes / 16);
-  const unsigned blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, 256 * 32);
+  // one piece per thread: the fastest shape on this chip (see launch_prep)
+  const unsigned blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, 0x7fffffff);
   hipEvent_t a, b;
   IFE_HIP(ctx, hipEventCreate(&a));
   IFE_HIP(ctx, hipEventCreate(&b));

@@ -78,7 +78,7 @@ typedef enum {
   /* planes per workgroup march of the feature kernel (default 64) */
   IFE_OPT_ZCHUNK = 4,
   /* samples per register block of the recursive-Gaussian kernels: 0 (default: chosen per
-   * axis -- z 10, four waves per SIMD; y 12; x 16), or 8, 10, 12, 16 for both strided axes
+   * axis -- z 12, y 12, x 16), or 8, 10, 12, 16 for both strided axes
    * (x keeps 16 unless 8 is asked for).  Never changes results. */
   IFE_OPT_IIR_BLOCK = 5,
   /* register blocks per checkpoint of the strided (z, y) line kernel: 2 (default, measured
