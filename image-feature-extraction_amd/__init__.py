@@ -47,6 +47,7 @@ EXPORTS = (
     "ife_get_kernel_times", "ife_reset_kernel_times", "ife_measure_stream",
     "ife_stage_prepare", "ife_stage_recursive_gaussian", "ife_stage_recursive_gaussian_batch",
     "ife_stage_features", "ife_stage_z_ck_bytes", "ife_stage_z_sweep", "ife_stage_z_combine",
+    "ife_stage_z_fused", "ife_stage_recursive_gaussian_quotient",
     "ife_multi_create", "ife_multi_destroy", "ife_multi_last_error", "ife_multi_set_option",
     "ife_multi_emphysema_features",
     "ife_sort_f32", "ife_equalized_edges_f32", "ife_equalized_edges_f64", "ife_dense_histogram_f32", "ife_roi_histograms", "ife_bag_image",
@@ -129,6 +130,10 @@ def load_library():
                                       C.POINTER(C.c_double), i32, vp, vp, C.POINTER(vp)]
     lib.ife_stage_z_combine.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), vd, i64, i64,
                                         C.POINTER(C.c_double), i32, i32, C.POINTER(vp)]
+    lib.ife_stage_z_fused.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(vp), vd, i64, i64,
+                                      C.POINTER(C.c_double), i32, i32, vp, vp, C.POINTER(vp)]
+    lib.ife_stage_recursive_gaussian_quotient.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                                          vd, i32, C.POINTER(C.c_double)]
     lib.ife_multi_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
     lib.ife_multi_destroy.argtypes = [vp]
     lib.ife_multi_destroy.restype = None
@@ -451,6 +456,32 @@ class Context:
         self._chk(self._lib.ife_stage_z_combine(
             self._h, n, ins, outs, C.byref(d), int(line0), int(nlines), sg, int(bool(has_lo)),
             int(bool(has_hi)), cks))
+
+    def stage_z_fused(self, direction, in_ptrs, out_ptrs, slab_shape_zyx, spacing, line0, nlines,
+                      sigmas, has_lo, has_hi, state_in_ptr, state_out_ptr, ck_ptrs):
+        """Sweep of `direction` (0 causal, 1 anticausal) and combine in one launch."""
+        n = len(in_ptrs)
+        d = _desc(slab_shape_zyx, spacing)
+        ins = (C.c_void_p * n)(*in_ptrs)
+        outs = (C.c_void_p * n)(*out_ptrs)
+        cks = (C.c_void_p * n)(*ck_ptrs)
+        sg = (C.c_double * n)(*[float(s) for s in sigmas])
+        self._chk(self._lib.ife_stage_z_fused(
+            self._h, int(direction), n, ins, outs, C.byref(d), int(line0), int(nlines), sg,
+            int(bool(has_lo)), int(bool(has_hi)), C.c_void_p(state_in_ptr or 0),
+            C.c_void_p(state_out_ptr), cks))
+
+    def stage_recursive_gaussian_quotient(self, num_ptrs, den_ptrs, out_ptrs, shape_zyx, spacing,
+                                          axis_xyz, sigmas):
+        """Last axis pass in its quotient form: out[j] = G(num[j]) / G(den[j]) (<= 4 jobs)."""
+        n = len(num_ptrs)
+        d = _desc(shape_zyx, spacing)
+        nums = (C.c_void_p * n)(*num_ptrs)
+        dens = (C.c_void_p * n)(*den_ptrs)
+        outs = (C.c_void_p * n)(*out_ptrs)
+        sg = (C.c_double * n)(*[float(s) for s in sigmas])
+        self._chk(self._lib.ife_stage_recursive_gaussian_quotient(
+            self._h, n, nums, dens, outs, C.byref(d), int(axis_xyz), sg))
 
     # ---- rows f1 / f2: sample columns, histogram edges, dense histograms --------------
     def sort_f32(self, values):

@@ -586,7 +586,8 @@ size_t zslab_ck_bytes(const ife_volume_desc *v) {
   const size_t L = (size_t)(v->nx * v->ny);
   return (size_t)zslab_pairs(v->nz) * 4 * L * 2 * sizeof(double);
 }
-// phase 0: causal sweep, 1: anticausal sweep, 2: combine
+// phase 0: causal sweep, 1: anticausal sweep, 2: combine, 3 / 4: fused with the causal /
+// anticausal recursion carried through the slab (zslab_fused_kernel)
 int launch_zslab(ife_ctx *ctx, int phase, int njobs, const float *const *in, float *const *out,
                  const ife_volume_desc *v, int64_t line0, int64_t nlines, const double *sigmas,
                  int has_lo, int has_hi, const void *state_in, void *state_out, void *const *ck) {
@@ -600,8 +601,8 @@ int launch_zslab(ife_ctx *ctx, int phase, int njobs, const float *const *in, flo
   if ((int64_t)2 * ZSLAB_K * L * 4 >= (int64_t)1 << 31 || L * 8 * 3 >= (int64_t)1 << 32)
     return fail(ctx, IFE_E_SIZE, "slab too large for the 32-bit offsets of the line kernels");
   if (!in || !sigmas || !ck) return fail(ctx, IFE_E_ARG, "null pointer");
-  const bool need_in = phase == 0 ? has_lo != 0 : phase == 1 ? has_hi != 0 : false;
-  if ((phase < 2 && !state_out) || (need_in && !state_in)) return fail(ctx, IFE_E_ARG, "null state buffer");
+  const bool need_in = (phase == 0 || phase == 3) ? has_lo != 0 : (phase == 1 || phase == 4) ? has_hi != 0 : false;
+  if ((phase != 2 && !state_out) || (need_in && !state_in)) return fail(ctx, IFE_E_ARG, "null state buffer");
   if ((reinterpret_cast<uintptr_t>(state_in) | reinterpret_cast<uintptr_t>(state_out)) % 8)
     return fail(ctx, IFE_E_ARG, "state buffers must be aligned to 8 bytes");
   const int64_t np = zslab_pairs(n);
@@ -609,12 +610,12 @@ int launch_zslab(ife_ctx *ctx, int phase, int njobs, const float *const *in, flo
   memset(&jobs, 0, sizeof jobs);
   for (int j = 0; j < njobs; ++j) {
     ZSlabJob &J = jobs.j[j];
-    if (!in[j] || !ck[j] || (phase == 2 && (!out || !out[j] || out[j] == in[j])))
+    if (!in[j] || !ck[j] || (phase >= 2 && (!out || !out[j] || out[j] == in[j])))
       return fail(ctx, IFE_E_ARG, "bad job buffers");
     if (reinterpret_cast<uintptr_t>(ck[j]) % 8 || reinterpret_cast<uintptr_t>(in[j]) % 4)
       return fail(ctx, IFE_E_ARG, "job buffers are misaligned");
     J.in = in[j] + line0;
-    J.out = phase == 2 ? out[j] + line0 : nullptr;
+    J.out = phase >= 2 ? out[j] + line0 : nullptr;
     double *cy = (double *)ck[j];
     double *ay = cy + np * 4 * L;
     J.cy = cy + line0; J.ay = ay + line0;
@@ -630,13 +631,17 @@ int launch_zslab(ife_ctx *ctx, int phase, int njobs, const float *const *in, flo
   g.njobs = njobs;
   g.ngroups = (int32_t)((nlines + 255) / 256);
   const dim3 grid((unsigned)((g.ngroups + 7) / 8 * 8 * njobs), 1, 1);
-  ProfScope ps(ctx, phase == 2 ? KK_ZSLAB_COMBINE : KK_ZSLAB_SWEEP);
+  ProfScope ps(ctx, phase >= 2 ? KK_ZSLAB_COMBINE : KK_ZSLAB_SWEEP);
 #define IFE_LAUNCH_ZSLAB(NS)                                                                        \
   do {                                                                                              \
     if (phase == 0)                                                                                 \
       hipLaunchKernelGGL((NS::zslab_causal_kernel<ZSLAB_K>), grid, dim3(256), 0, ctx->stream, jobs, g); \
     else if (phase == 1)                                                                            \
       hipLaunchKernelGGL((NS::zslab_anti_kernel<ZSLAB_K>), grid, dim3(256), 0, ctx->stream, jobs, g);   \
+    else if (phase == 3)                                                                            \
+      hipLaunchKernelGGL((NS::zslab_fused_kernel<ZSLAB_K, 0>), grid, dim3(256), 0, ctx->stream, jobs, g); \
+    else if (phase == 4)                                                                            \
+      hipLaunchKernelGGL((NS::zslab_fused_kernel<ZSLAB_K, 1>), grid, dim3(256), 0, ctx->stream, jobs, g); \
     else                                                                                            \
       hipLaunchKernelGGL((NS::zslab_combine_kernel<ZSLAB_K>), grid, dim3(256), 0, ctx->stream, jobs, g); \
   } while (0)
@@ -1466,6 +1471,33 @@ int ife_stage_z_combine(ife_ctx *ctx, int njobs, const float *const *in, float *
   if ((rc = check_vol(ctx, slab, false))) return rc;
   return launch_zslab(ctx, 2, njobs, in, out, slab, line0, nlines, sigmas, has_lo, has_hi, nullptr,
                       nullptr, ck);
+}
+
+int ife_stage_z_fused(ife_ctx *ctx, int direction, int njobs, const float *const *in,
+                      float *const *out, const ife_volume_desc *slab, int64_t line0, int64_t nlines,
+                      const double *sigmas, int has_lo, int has_hi, const void *state_in,
+                      void *state_out, void *const *ck) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_vol(ctx, slab, false))) return rc;
+  if (direction != 0 && direction != 1) return fail(ctx, IFE_E_ARG, "direction must be 0 (causal) or 1 (anticausal)");
+  return launch_zslab(ctx, 3 + direction, njobs, in, out, slab, line0, nlines, sigmas, has_lo, has_hi,
+                      state_in, state_out, ck);
+}
+
+int ife_stage_recursive_gaussian_quotient(ife_ctx *ctx, int njobs, const float *const *num,
+                                          const float *const *den, float *const *out,
+                                          const ife_volume_desc *vol, int axis, const double *sigmas) {
+  int rc = bind(ctx);
+  if (rc) return rc;
+  if ((rc = check_vol(ctx, vol, false))) return rc;
+  if (!num || !den || !out || !sigmas) return fail(ctx, IFE_E_ARG, "null pointer");
+  if (axis != 1 && axis != 2) return fail(ctx, IFE_E_ARG, "the quotient form runs on the strided axes: 1 (y) or 2 (z)");
+  for (int j = 0; j < njobs; ++j)
+    if (!(sigmas[j] > 0.0)) return fail(ctx, IFE_E_ARG, "sigma must be positive");
+  if ((axis == 1 ? vol->ny : vol->nz) < 4)
+    return fail(ctx, IFE_E_SIZE, "the recursive Gaussian needs at least 4 voxels along axis %d", axis);
+  return launch_iir(ctx, vol, axis, njobs, num, out, sigmas, 1, nullptr, den);
 }
 
 int ife_stage_features(ife_ctx *ctx, const float *num, const float *den, const void *mask,

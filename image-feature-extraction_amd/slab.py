@@ -25,13 +25,17 @@ Per step and rank (S scales, nf = 2 fields with a mask, G line groups per scale)
 
   prepare                       tc = image*mask, cf = float(mask)                (local)
   chain stream, items (scale group q, line group g) in expected-arrival order:
-      C(q, g): [recv state from r-1] causal sweep     [send state to r+1]
-      A(q, g): [recv state from r+1] anticausal sweep [send state to r-1]
+      the direction whose state reaches this rank FIRST (causal in the lower half of the
+      ranks, anticausal in the upper) as a lean sweep: [recv state] one recursion step per
+      sample, checkpoints [send state];
+      the other direction FUSED with the combine: [recv state] that recursion carried through
+      the slab, the first one rebuilt from its checkpoints, the Z output written [send state].
+      Three recursion steps per sample and rank (round 2: two sweeps and a combine, four).
   bulk stream, per scale group (all scales up to four ranks, else one scale):
-      combine (Z output), X pass, Y pass, halo exchange, features               (local)
+      X pass, Y pass (stores numerator / denominator), halo exchange, features  (local)
 
 Bytes over xGMI per boundary, direction and step: 32 B x nx*ny x S x nf (512^2, 3 scales,
-2 fields: 50 MB) + one plane of 2 fields per scale (6 MB); neighbours only.
+2 fields: 50 MB) + one plane of the smoothed value per scale (3 MB); neighbours only.
 
 The order of the sweeps on a rank is static: sorted by the hop count after which the state
 can arrive (causal item i at rank r: r + i; anticausal: W-1-r + i; ties causal first).
@@ -102,6 +106,23 @@ class HipStages:
                                      spacing, line0, nlines, sigmas, has_neighbour,
                                      state_in.data_ptr() if has_neighbour else None,
                                      state_out.data_ptr(), [c.data_ptr() for c in cks])
+
+    def z_fused(self, direction, srcs_ext, pad_lo, nzl, dsts, spacing, sigmas, line0, nlines, has_lo, has_hi,
+                state_in, state_out, cks):
+        """The sweep of `direction` and the combine in one launch (C-ABI ife_stage_z_fused): for the
+        direction whose state arrives last; needs the other direction's checkpoints in cks."""
+        own = [t[pad_lo:pad_lo + nzl] for t in srcs_ext]
+        has_nb = has_lo if direction == 0 else has_hi
+        self.chain_ctx.stage_z_fused(direction, [t.data_ptr() for t in own], [t.data_ptr() for t in dsts],
+                                     tuple(own[0].shape), spacing, line0, nlines, sigmas, has_lo, has_hi,
+                                     state_in.data_ptr() if has_nb else None, state_out.data_ptr(),
+                                     [c.data_ptr() for c in cks])
+
+    def gaussian_quotient(self, nums, dens, dsts, spacing, axis, sigmas):
+        """Last axis pass of the normalized convolution: dsts[j] = G(nums[j]) / G(dens[j])."""
+        self.ctx.stage_recursive_gaussian_quotient([t.data_ptr() for t in nums], [t.data_ptr() for t in dens],
+                                                   [t.data_ptr() for t in dsts], tuple(dsts[0].shape),
+                                                   spacing, axis, sigmas)
 
     def z_combine(self, srcs_ext, pad_lo, nzl, dsts, spacing, sigmas, has_lo, has_hi, cks):
         own = [t[pad_lo:pad_lo + nzl] for t in srcs_ext]
@@ -347,9 +368,13 @@ class SlabEngine:
         # work of step t still reads its own -- in a stream of volumes the chains' start-up
         # (W-1 hops) then hides behind the previous volume's X, Y and feature passes
         self.src = [[f(self.pad_lo + nzl + self.pad_hi, ny, nx) for _ in range(nf)] for _ in range(2)]
-        self.zo = [[f(nzl, ny, nx) for _ in range(nf)] for _ in range(S)]   # Z-pass output
+        # Z-pass output: written on the chain stream (fused kernels) while the X pass of the step
+        # before may still read its own, so it alternates between steps like src and ck
+        self.zo = [[[f(nzl, ny, nx) for _ in range(nf)] for _ in range(S)] for _ in range(2)]
         self.xo = [[f(nzl, ny, nx) for _ in range(nf)] for _ in range(S)]   # X-pass output
-        self.pad = [[f(nzl + 2, ny, nx) for _ in range(nf)] for _ in range(S)]  # Y output + halo planes
+        self.pad = [f(nzl + 2, ny, nx) for _ in range(S)]  # smoothed value S (Y output) + halo planes
+        # the direction whose state reaches this rank first runs as a lean sweep, the other fused
+        self.lean = 0 if rank <= world - 1 - rank else 1
         ckb = stages.ck_bytes((nzl, ny, nx))
         self.ck = [[[alloc((ckb,), "uint8") for _ in range(nf)] for _ in range(S)] for _ in range(2)]
         self.step = 0
@@ -386,7 +411,7 @@ class SlabEngine:
 
         par = self.step % 2
         self.step += 1
-        src, ck = self.src[par], self.ck[par]
+        src, ck, zo = self.src[par], self.ck[par], self.zo[par]
 
         # A receive is ENQUEUED where its sweep stands in the schedule, never earlier: the
         # schedule is a topological order of the whole job (every dependency has a smaller key
@@ -417,9 +442,14 @@ class SlabEngine:
                 if self.sent[d][i] is not None:  # last step's send still reads sout
                     self.sent[d][i].wait()
                     self.sent[d][i] = None
-                st.z_sweep(d, [src[k] for _ in ss for k in range(nf)], self.pad_lo, self.nzl, sp,
-                           [self.sigmas[s] for s in ss for _ in range(nf)], l0, nl, has_nb, sin, sout,
-                           [ck[s][k] for s in ss for k in range(nf)])
+                srcs = [src[k] for _ in ss for k in range(nf)]
+                sgs = [self.sigmas[s] for s in ss for _ in range(nf)]
+                cks = [ck[s][k] for s in ss for k in range(nf)]
+                if d == self.lean:
+                    st.z_sweep(d, srcs, self.pad_lo, self.nzl, sp, sgs, l0, nl, has_nb, sin, sout, cks)
+                else:  # its state arrives last: carried through the slab, the other from checkpoints
+                    st.z_fused(d, srcs, self.pad_lo, self.nzl, [zo[s][k] for s in ss for k in range(nf)],
+                               sp, sgs, l0, nl, has_lo, has_hi, sin, sout, cks)
                 swept[d][i] = rec(chain)
                 self.consumed[d][i] = swept[d][i]
                 if d == 0 and has_hi:
@@ -428,26 +458,29 @@ class SlabEngine:
                     self.sent[d][i] = comm.isend_down(sout)
 
         first = 0 if has_lo else 1
+        fat = 1 - self.lean
         for qs in self.bulk_groups:
             ss = [s for q in qs for s in self.scale_groups[q]]
             for i, (qi, g) in enumerate(self.items):
                 if qi in qs:
-                    wait(bulk, swept[0][i])
-                    wait(bulk, swept[1][i])
+                    wait(bulk, swept[fat][i])  # the fused kernels have written this group's Z output
             sg = [self.sigmas[s] for s in ss for _ in range(nf)]
             jobs = lambda bufs: [bufs[s][k] for s in ss for k in range(nf)]
-            st.z_combine([src[k] for s in ss for k in range(nf)], self.pad_lo, self.nzl,
-                         jobs(self.zo), sp, sg, has_lo, has_hi, jobs(ck))
+            st.gaussian_axis_batch(jobs(zo), jobs(self.xo), sp, 0, sg)
             if qs is self.bulk_groups[-1]:
-                self.free[par] = rec(bulk)  # the last reader of this step's src / ck set
-            st.gaussian_axis_batch(jobs(self.zo), jobs(self.xo), sp, 0, sg)
-            st.gaussian_axis_batch(jobs(self.xo), [self.pad[s][k][1:self.nzl + 1] for s in ss
-                                                   for k in range(nf)], sp, 1, sg)
-            pads = jobs(self.pad)
+                self.free[par] = rec(bulk)  # the last reader of this step's Z output (src and ck are
+                #                             only read on the chain stream, in order)
+            own = [self.pad[s][1:self.nzl + 1] for s in ss]
+            if nf == 2:  # the last pass stores numerator / denominator: one field from here on
+                st.gaussian_quotient([self.xo[s][0] for s in ss], [self.xo[s][1] for s in ss], own, sp, 1,
+                                     [self.sigmas[s] for s in ss])
+            else:
+                st.gaussian_axis_batch([self.xo[s][0] for s in ss], own, sp, 1, [self.sigmas[s] for s in ss])
+            pads = [self.pad[s] for s in ss]
             comm.halo([p[1] for p in pads], [p[self.nzl] for p in pads],
                       [p[0] for p in pads], [p[self.nzl + 1] for p in pads])
             for s in ss:
-                st.features(self.pad[s][0][first:], self.pad[s][1][first:] if self.has_mask else None,
+                st.features(self.pad[s][first:], None,
                             mask_slab[self.pad_lo:self.pad_lo + self.nzl] if self.has_mask else None,
                             slab_shape, sp,
                             1 if has_lo else 0, 1 if has_hi else 0, out[s], self.layout)

@@ -271,7 +271,8 @@ int ife_stage_recursive_gaussian_batch(ife_ctx *ctx, int njobs, const float *con
 /* The Z pass of a Z-slab with the recursion state handed across the slab boundaries (the
  * reference has no counterpart: its RecursiveGaussianImageFilter sees whole lines,
  * NormalizedGaussianConvolutionImageFilter.hxx:51-55).  A slab holds planes [z0, z1) of every
- * Z line; `in` are njobs (<= 8) float slabs [nz][ny][nx] with one sigma each.  Three calls:
+ * Z line; `in` are njobs (<= 8) float slabs [nz][ny][nx] with one sigma each.  Three calls
+ * (or two: ife_stage_z_fused below replaces the later sweep and the combine):
  *   ife_stage_z_sweep(direction 0): causal recursion upwards.  has_neighbour = a slab below
  *     exists and state_in holds its outgoing record; else ITK's start-of-line rule applies.
  *     Leaves the causal checkpoints in ck[job] and the state at z1 in state_out.
@@ -302,6 +303,24 @@ int ife_stage_z_sweep(ife_ctx *ctx, int direction, int njobs, const float *const
 int ife_stage_z_combine(ife_ctx *ctx, int njobs, const float *const *in, float *const *out,
                         const ife_volume_desc *slab, int64_t line0, int64_t nlines,
                         const double *sigmas, int has_lo, int has_hi, void *const *ck);
+/* Sweep of `direction` and combine in one: for the direction whose state reaches a slab LAST.
+ * The recursion of `direction` runs through the slab from state_in (or ITK's border rule where
+ * that side has no neighbour: has_lo for direction 0, has_hi for direction 1), the other
+ * direction's values come from the checkpoints its ife_stage_z_sweep left in ck[job]; writes
+ * float(causal + anticausal) to out[job] and the carried state to state_out.  Three recursion
+ * steps per sample for the slab (one lean sweep + this) instead of four (two sweeps + combine),
+ * the same operations on every sample: same bits. */
+int ife_stage_z_fused(ife_ctx *ctx, int direction, int njobs, const float *const *in,
+                      float *const *out, const ife_volume_desc *slab, int64_t line0, int64_t nlines,
+                      const double *sigmas, int has_lo, int has_hi, const void *state_in,
+                      void *state_out, void *const *ck);
+/* The last axis pass of the normalized convolution in its quotient form
+ * (NormalizedGaussianConvolutionImageFilter.hxx:51-61: the two smoothings and the Div functor):
+ * job j filters num[j] and den[j] along `axis` (1 = y or 2 = z) with sigmas[j] and stores
+ * numerator / denominator (denominator == 0: the functor's max()) in out[j].  njobs <= 4. */
+int ife_stage_recursive_gaussian_quotient(ife_ctx *ctx, int njobs, const float *const *num,
+                                          const float *const *den, float *const *out,
+                                          const ife_volume_desc *vol, int axis, const double *sigmas);
 
 /* Everything after the smoothing (ImageToEmphysemaFeaturesFilter.hxx:27-54 plus the
  * Divide of NormalizedGaussianConvolutionImageFilter.hxx:57-61) on a slab of slab->nz

@@ -113,6 +113,29 @@ class OracleStages:
                     yo[k][j] = yh[j]
             self.store[(cks[k].data_ptr(), direction, line0)] = out
 
+    def z_fused(self, direction, srcs_ext, pad_lo, nzl, dsts, spacing, sigmas, line0, nlines, has_lo, has_hi,
+                state_in, state_out, cks):
+        """The later direction's sweep and the combine in one: the recursion of `direction` from
+        its incoming state, the other direction's values as its sweep left them."""
+        import torch
+        self.z_sweep(direction, srcs_ext, pad_lo, nzl, spacing, sigmas, line0, nlines,
+                     has_lo if direction == 0 else has_hi, state_in, state_out, cks)
+        for k, dst in enumerate(dsts):
+            mine = self.store[(cks[k].data_ptr(), direction, line0)]
+            other = self.store[(cks[k].data_ptr(), 1 - direction, line0)]
+            causal, anti = (mine, other) if direction == 0 else (other, mine)
+            flat = dst.view(dst.shape[0], -1)
+            flat[:, line0:line0 + nlines] = torch.from_numpy((causal + anti).astype(np.float32))
+
+    def gaussian_quotient(self, nums, dens, dsts, spacing, axis, sigmas):
+        import torch
+        for num, den, dst, sigma in zip(nums, dens, dsts, sigmas):
+            n = self.o.recursive_gaussian_axis(num.contiguous().numpy(), axis, sigma, spacing)
+            d = self.o.recursive_gaussian_axis(den.contiguous().numpy(), axis, sigma, spacing)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                q = np.where(d != 0, n / np.where(d != 0, d, 1), np.finfo(np.float32).max).astype(np.float32)
+            dst.copy_(torch.from_numpy(q))
+
     def z_combine(self, srcs_ext, pad_lo, nzl, dsts, spacing, sigmas, has_lo, has_hi, cks):
         import torch
         for k, dst in enumerate(dsts):
@@ -368,3 +391,97 @@ def test_z_slab_stage_kernels_match_single_device_pass(ife, oracle, synth):
         got = np.concatenate([o.cpu().numpy() for o in outs], 0)
         ctx.close()
         np.testing.assert_array_equal(got, ref, err_msg=str(bounds))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lean_rule", ["half", "all_causal", "all_anti"])
+def test_z_slab_fused_kernels_match_single_device_pass(ife, oracle, synth, lean_rule):
+    """ife_stage_z_fused: per slab one lean sweep (the direction whose state arrives first) and
+    the other direction carried through the slab together with the combine.  Whatever direction
+    a slab takes as its lean one -- the engine's rule (lower half causal, upper half
+    anticausal), or the same for all -- the stitched result equals the oracle's Z pass bit for
+    bit: cuts of awkward sizes, slabs of 4 planes, one slab alone, two sigmas in one launch."""
+    import torch
+    shape, sigmas, spacing = (61, 20, 70), [2.5, 0.9], (1.0, 1.0, 0.8)
+    vol = synth.volume_f32(shape, 5)
+    refs = [oracle.recursive_gaussian_axis(vol, 2, sg, spacing) for sg in sigmas]
+    nz, ny, nx = shape
+    L = ny * nx
+    nj = len(sigmas)
+    slab_mod = importlib.import_module(PKG + ".slab")
+    for bounds in ([0, 61], [0, 4, 61], [0, 25, 30, 61], [0, 13, 26, 39, 61], [0, 57, 61]):
+        W = len(bounds) - 1
+        ctx = ife.Context(0)
+        ext, slabs = [], []
+        for r in range(W):
+            lo, hi = slab_mod.overlap(r, W)
+            e = torch.from_numpy(vol[bounds[r] - lo:bounds[r + 1] + hi].copy()).cuda()
+            ext.append(e)
+            slabs.append(e[lo:lo + bounds[r + 1] - bounds[r]])
+        outs = [[torch.full_like(s, float("nan")) for _ in range(nj)] for s in slabs]
+        cks = [[torch.empty(ctx.stage_z_ck_bytes(tuple(s.shape)), dtype=torch.uint8, device="cuda")
+                for _ in range(nj)] for s in slabs]
+        state = lambda: torch.zeros(nj * ife.Z_STATE_BYTES * L, dtype=torch.uint8, device="cuda")
+        up, dn = [state() for _ in range(W)], [state() for _ in range(W)]
+        lean = {"half": [0 if r <= W - 1 - r else 1 for r in range(W)],
+                "all_causal": [0] * W, "all_anti": [1] * W}[lean_rule]
+
+        def step(r, d):
+            shp = tuple(slabs[r].shape)
+            ins = [slabs[r].data_ptr()] * nj
+            ck = [c.data_ptr() for c in cks[r]]
+            sin = (up[r - 1] if r > 0 else None) if d == 0 else (dn[r + 1] if r < W - 1 else None)
+            sout = up[r] if d == 0 else dn[r]
+            if d == lean[r]:
+                ctx.stage_z_sweep(d, ins, shp, spacing, 0, L, sigmas, sin is not None,
+                                  sin.data_ptr() if sin is not None else None, sout.data_ptr(), ck)
+            else:
+                ctx.stage_z_fused(d, ins, [o.data_ptr() for o in outs[r]], shp, spacing, 0, L, sigmas,
+                                  r > 0, r < W - 1, sin.data_ptr() if sin is not None else None,
+                                  sout.data_ptr(), ck)
+
+        # a fused step needs its slab's lean sweep first: run every lean sweep it can, chain by chain
+        done = set()
+        pending = [(r, d) for r in range(W) for d in (0, 1)]
+        while pending:
+            progressed = False
+            for r, d in list(pending):
+                upstream = (r - 1, 0) if d == 0 else (r + 1, 1)
+                have_state = upstream[0] < 0 or upstream[0] >= W or upstream in done
+                have_ck = d == lean[r] or (r, lean[r]) in done
+                if have_state and have_ck:
+                    step(r, d)
+                    done.add((r, d))
+                    pending.remove((r, d))
+                    progressed = True
+            assert progressed, "dependency cycle in the test's own ordering"
+        torch.cuda.synchronize()
+        for j in range(nj):
+            got = np.concatenate([o[j].cpu().numpy() for o in outs], 0)
+            np.testing.assert_array_equal(got, refs[j], err_msg="%s %s sigma %g" % (bounds, lean_rule, sigmas[j]))
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_stage_quotient_pass_equals_two_passes_and_divide(ife, oracle, synth):
+    """ife_stage_recursive_gaussian_quotient (the slab engine's last axis pass) against the
+    oracle's two smoothings and ITK's Div functor, a vanishing denominator included."""
+    import torch
+    shape, spacing = (13, 70, 66), (0.9, 1.1, 1.0)
+    num = synth.volume_f32(shape, 3)
+    den = (synth.mask_ellipsoids(shape) > 0).astype(np.float32)
+    den[:, :, :8] = 0  # whole lines without certainty: the quotient is the functor's max()
+    sigmas = [1.0, 2.5]
+    ctx = ife.Context(0)
+    dn, dd = torch.from_numpy(num).cuda(), torch.from_numpy(den).cuda()
+    outs = [torch.empty_like(dn) for _ in sigmas]
+    ctx.stage_recursive_gaussian_quotient([dn.data_ptr()] * 2, [dd.data_ptr()] * 2, [o.data_ptr() for o in outs],
+                                          shape, spacing, 1, sigmas)
+    torch.cuda.synchronize()
+    for o, sg in zip(outs, sigmas):
+        n = oracle.recursive_gaussian_axis(num, 1, sg, spacing)
+        d = oracle.recursive_gaussian_axis(den, 1, sg, spacing)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            want = np.where(d != 0, n / np.where(d != 0, d, 1), np.finfo(np.float32).max).astype(np.float32)
+        np.testing.assert_array_equal(o.cpu().numpy(), want)
+    ctx.close()
