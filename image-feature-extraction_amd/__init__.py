@@ -49,7 +49,8 @@ EXPORTS = (
     "ife_stage_features", "ife_stage_z_ck_bytes", "ife_stage_z_sweep", "ife_stage_z_combine",
     "ife_stage_z_fused", "ife_stage_recursive_gaussian_quotient",
     "ife_multi_create", "ife_multi_destroy", "ife_multi_last_error", "ife_multi_set_option",
-    "ife_multi_emphysema_features",
+    "ife_multi_emphysema_features", "ife_multi_emphysema_features_begin",
+    "ife_multi_emphysema_features_fetch", "ife_multi_emphysema_features_end",
     "ife_sort_f32", "ife_equalized_edges_f32", "ife_equalized_edges_f64", "ife_dense_histogram_f32", "ife_roi_histograms", "ife_bag_image",
     "ife_samples_create", "ife_samples_destroy", "ife_samples_count", "ife_samples_clear",
     "ife_samples_add_features", "ife_samples_add_image", "ife_samples_sort",
@@ -141,6 +142,9 @@ def load_library():
     lib.ife_multi_last_error.restype = C.c_char_p
     lib.ife_multi_set_option.argtypes = [vp, i32, i32]
     lib.ife_multi_emphysema_features.argtypes = [vp, vp, i32, vp, i32, vd, C.POINTER(C.c_float), i32, f32p, i32]
+    lib.ife_multi_emphysema_features_begin.argtypes = [vp, vp, i32, vp, i32, vd, C.POINTER(C.c_float), i32, i32]
+    lib.ife_multi_emphysema_features_fetch.argtypes = [vp, i32, f32p]
+    lib.ife_multi_emphysema_features_end.argtypes = [vp]
     lib.ife_get_kernel_times.argtypes = [vp, C.POINTER(KernelTime), i32]
     lib.ife_reset_kernel_times.argtypes = [vp]
     lib.ife_measure_stream.argtypes = [vp, i32, vp, vp, C.c_size_t, i32, C.POINTER(C.c_double)]
@@ -598,6 +602,31 @@ class Multi:
             self._h, image.ctypes.data, _IMG_DT[image.dtype], mptr, mdt, C.byref(d), sig,
             len(sigmas), out.ctypes.data, layout))
         return out
+
+
+    def emphysema_features_stream(self, image, mask, sigmas, spacing=(1.0, 1.0, 1.0), layout=INTERLEAVED):
+        """Generator over the scales: one upload and prepass, every scale enqueued on every
+        device, then one blocking fetch per scale (ife_multi_emphysema_features_begin / _fetch /
+        _end) -- the scale loop of tools/ExtractFeatures.cxx:132-154 over several devices."""
+        image = np.ascontiguousarray(image)
+        if image.dtype not in _IMG_DT:
+            image = image.astype(np.float32)
+        mdt, mptr = U8, None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask)
+            mdt, mptr = _MSK_DT[mask.dtype], mask.ctypes.data
+        d = _desc(image.shape, spacing)
+        sig = (C.c_float * len(sigmas))(*[float(s) for s in sigmas])
+        shp = image.shape + (8,) if layout == INTERLEAVED else (8,) + image.shape
+        self._chk(self._lib.ife_multi_emphysema_features_begin(
+            self._h, image.ctypes.data, _IMG_DT[image.dtype], mptr, mdt, C.byref(d), sig, len(sigmas), layout))
+        try:
+            for k in range(len(sigmas)):
+                out = np.empty(shp, np.float32)
+                self._chk(self._lib.ife_multi_emphysema_features_fetch(self._h, k, out.ctypes.data))
+                yield out
+        finally:
+            self._chk(self._lib.ife_multi_emphysema_features_end(self._h))
 
 
 class Samples:

@@ -16,6 +16,8 @@
 // Multiply once and enqueues every scale on the device (ife_emphysema_features_begin); each
 // Update() then only fetches its scale, so writing scale k overlaps the device work of the
 // later ones.  Without the hint every scale is one self-contained call, as in the reference.
+// The same holds with IFE_DEVICES (several devices, Z-slabs): one upload of the slabs and one
+// prepass for all announced scales (ife_multi_emphysema_features_begin), a fetch per scale.
 #ifndef __ImageToEmphysemaFeaturesFilter_h
 #define __ImageToEmphysemaFeaturesFilter_h
 
@@ -60,20 +62,31 @@ class ImageToEmphysemaFeaturesFilter {
     out_->CopyInformation(image_);
     out_->SetNumberOfComponentsPerPixel(numFeatures);  // .hxx:83-90
     out_->Allocate();
-    if (ife_multi *multi = e.multi()) {  // IFE_DEVICES: Z-slabs over several devices
-      const float sig1 = (float)sigma_;
-      e.check_multi(ife_multi_emphysema_features(
-                        multi, image_->GetBufferPointer(), ife::host::ImageDType<PixelType>::value,
-                        mask_->GetBufferPointer(),
-                        ife::host::MaskDType<typename InputMaskType::PixelType>::value, &d, &sig1, 1,
-                        out_->GetBufferPointer(), IFE_INTERLEAVED),
-                    "ImageToEmphysemaFeaturesFilter");
-      dirty_ = false;
-      return;
-    }
     int which = -1;
     for (size_t k = 0; k < scales_.size(); ++k)
       if (scales_[k] == (float)sigma_) { which = (int)k; break; }
+    if (ife_multi *multi = e.multi()) {  // IFE_DEVICES: Z-slabs over several devices
+      const int idt = ife::host::ImageDType<PixelType>::value;
+      const int mdt = ife::host::MaskDType<typename InputMaskType::PixelType>::value;
+      if (which >= 0) {  // the announced schedule: one upload and prepass, every scale enqueued, fetched per scale
+        if (!streaming_) {
+          e.check_multi(ife_multi_emphysema_features_begin(multi, image_->GetBufferPointer(), idt,
+                                                           mask_->GetBufferPointer(), mdt, &d, scales_.data(),
+                                                           (int)scales_.size(), IFE_INTERLEAVED),
+                        "ImageToEmphysemaFeaturesFilter");
+          streaming_ = true;
+        }
+        e.check_multi(ife_multi_emphysema_features_fetch(multi, which, out_->GetBufferPointer()),
+                      "ImageToEmphysemaFeaturesFilter");
+      } else {
+        const float sig1 = (float)sigma_;
+        e.check_multi(ife_multi_emphysema_features(multi, image_->GetBufferPointer(), idt, mask_->GetBufferPointer(),
+                                                   mdt, &d, &sig1, 1, out_->GetBufferPointer(), IFE_INTERLEAVED),
+                      "ImageToEmphysemaFeaturesFilter");
+      }
+      dirty_ = false;
+      return;
+    }
     if (which >= 0) {  // the announced schedule: everything is started once, fetched per scale
       if (!streaming_) {
         e.check(ife_emphysema_features_begin(
@@ -107,7 +120,9 @@ class ImageToEmphysemaFeaturesFilter {
  private:
   void EndStream() {
     if (streaming_) {
-      (void)ife_emphysema_features_end(ife::host::Engine::Instance().ctx());
+      ife::host::Engine &e = ife::host::Engine::Instance();
+      if (ife_multi *multi = e.multi()) (void)ife_multi_emphysema_features_end(multi);
+      else (void)ife_emphysema_features_end(e.ctx());
       streaming_ = false;
     }
   }

@@ -349,6 +349,17 @@ int ife_multi_set_option(ife_multi *m, int option, int value);
 int ife_multi_emphysema_features(ife_multi *m, const void *image, int image_dtype,
                                  const void *mask, int mask_dtype, const ife_volume_desc *vol,
                                  const float *sigmas, int n_sigmas, float *out, int layout);
+/* The scale loop of tools/ExtractFeatures.cxx:132-154 over several devices, one scale at a
+ * time to the host (the multi-device form of ife_emphysema_features_begin / _fetch / _end):
+ * _begin uploads every slab once, runs Cast + Multiply once and enqueues every scale on every
+ * device without waiting; _fetch(k) blocks until scale k of every slab has been copied into
+ * `out` (that scale's whole volume: nx*ny*nz*8 floats of host memory) on a stream of its own,
+ * while the later scales keep computing; _end drains.  IFE_E_STATE out of sequence. */
+int ife_multi_emphysema_features_begin(ife_multi *m, const void *image, int image_dtype,
+                                       const void *mask, int mask_dtype, const ife_volume_desc *vol,
+                                       const float *sigmas, int n_sigmas, int layout);
+int ife_multi_emphysema_features_fetch(ife_multi *m, int scale, float *out);
+int ife_multi_emphysema_features_end(ife_multi *m);
 
 /* ---- rows f1 / f2: sample columns, equalizing histogram edges, dense histograms ------- *
  * The immediate consumer of the feature volume.  The samples never

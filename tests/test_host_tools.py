@@ -172,6 +172,7 @@ def test_extract_features_over_several_devices(built, tmp_path, synth):
     for devs in (None, "0,0,0"):
         env = dict(os.environ)
         env.pop("IFE_DEVICES", None)
+        env["IFE_MULTI_TRACE"] = "1"
         if devs:
             env["IFE_DEVICES"] = devs
         base = str(tmp_path / ("o" + (devs or "single").replace(",", "")))
@@ -179,6 +180,9 @@ def test_extract_features_over_several_devices(built, tmp_path, synth):
                             str(tmp_path / "m.nii.gz"), "-o", base, "-s", "1", "-s", "2.5"],
                            capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr
+        # the tool announces its scales (SetScales): ONE upload and prepass for both of them
+        # (tools/ExtractFeatures.cxx:132-154 re-executes everything per scale)
+        assert r.stderr.count("ife_multi: upload and prepass") == (1 if devs else 0), r.stderr
         outs.append([niftiio.read(base + "_scale_%s%s.nii.gz" % (sc, f))[0]
                      for sc in ("1.000000", "2.500000") for f in ("GaussianBlur", "Eigenvalue1", "FrobeniusNorm")])
     for a, b in zip(*outs):
