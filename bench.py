@@ -92,7 +92,13 @@ def parse():
                          "bar; 0 double evaluation, bit-faithful to the oracle")
     ap.add_argument("--iir-block", type=int, default=None)
     ap.add_argument("--iir-ckpt", type=int, default=None)
-    ap.add_argument("--iir-fma", action="store_true", help="opt-in fused recurrences (not bit-exact)")
+    ap.add_argument("--iir-fma", action="store_true",
+                    help="the RELAXED line, never the headline: fused multiply-adds in the line "
+                         "recurrences (IFE_OPT_IIR_FMA, not the reference's arithmetic).  The run then "
+                         "also compares the whole output with the oracle at full size and prints the "
+                         "MAXIMUM eigenvalue error (config.iir_fma = 1, `relaxed` in the JSON line)")
+    ap.add_argument("--relaxed-bar", type=float, default=None,
+                    help="--iir-fma: fail if the maximum eigenvalue error / |lambda1| exceeds this")
     ap.add_argument("--zchunk", type=int, default=None)
     ap.add_argument("--const-lines", type=int, default=0, choices=[0, 1],
                     help="IFE_OPT_CONST_LINES.  The headline keeps it OFF: with the all-ones mask of "
@@ -234,6 +240,45 @@ def cpu_baseline(synth, seed, sigmas, edge):
                       "%.1f s of CPU work" % (edge, list(sigmas), dt)}
 
 
+def relaxed_error(runner, synth, seed, sigmas, args):
+    """What the fused recurrences cost in accuracy, over EVERY voxel of the bench volume at every
+    scale, against the oracle (exact arithmetic, double trigonometry): the maximum, not a
+    quantile.  The smoothed value may differ by float ulps; the second differences amplify
+    that, so the eigenvalue error relative to |lambda1| is what is printed (and asserted
+    against --relaxed-bar)."""
+    from oracle import parity, pyoracle
+    pyoracle.build()
+    pyoracle.set_threads(min(os.cpu_count() or 1, 16))
+    shape = runner.shape
+    img = synth.volume_i16(shape, seed) if runner.i16 else synth.volume_f32(shape, seed)
+    mask = (np.minimum(synth.mask_ellipsoids(shape), 1).astype(np.uint8) if args.mask == "ellipsoids"
+            else np.ones(shape, np.uint8))
+    res = {"iir_fma": 1, "compared": "every voxel of the volume, all scales, against the oracle",
+           "scales": []}
+    worst = 0.0
+    for s, sigma in enumerate(sigmas):
+        got = runner.d_out[s].cpu().numpy()
+        ref = pyoracle.emphysema_features(img.astype(np.float32), mask, float(sigma), tuple(args.spacing))
+        p = parity.eig_parity(got, ref, tie_tol=2e-5)
+        ds = np.abs(got[..., 0].astype(np.float64) - ref[..., 0])
+        scale = np.maximum(np.abs(ref[..., 0]).astype(np.float64), 1e-30)
+        lam = np.maximum(np.abs(ref[..., 2]).astype(np.float64), 1e-30)
+        ee = np.abs(np.sort(got[..., 2:5].astype(np.float64), -1) - np.sort(ref[..., 2:5].astype(np.float64), -1)).max(-1) / lam
+        res["scales"].append({"sigma": sigma, "max_eig_err_rel_lambda1": p["max_err"],
+                              "voxels_beyond_1e-5": int((ee > 1e-5).sum()), "voxels": int(ee.size),
+                              "smoothed_value_differs_at": int((got[..., 0] != ref[..., 0]).sum()),
+                              "max_smoothed_value_rel_err": float((ds / scale).max()),
+                              "order_diff": p["order_diff"]})
+        worst = max(worst, p["max_err"])
+        del got, ref, ee, ds
+    res["max_eig_err_rel_lambda1"] = worst
+    res["bar"] = args.relaxed_bar
+    if args.relaxed_bar is not None and not worst <= args.relaxed_bar:
+        raise SystemExit("relaxed line: maximum eigenvalue error %.3g |lambda1| exceeds the bar %.3g"
+                         % (worst, args.relaxed_bar))
+    return res
+
+
 def measured_stream_gbs(torch, ctx, dev, nbytes=4 << 30, reps=5):
     """The box's own streaming rates with this library's access shape (16 B per lane,
     non-temporal, grid-stride; ife_measure_stream): a 4-GiB fill (bytes written per second) and
@@ -326,6 +371,9 @@ def main():
         torch.cuda.synchronize()
         shortcut_ms = (time.perf_counter() - t1) / 3 * 1e3
         runner.ctx.set_option(pkg.OPT_CONST_LINES, 0)
+    relaxed = None
+    if args.iir_fma and not use_dist:
+        relaxed = relaxed_error(runner, synth, seed, sigmas, args)
     fill_gbs = copy_gbs = None
     if rank == 0 and not use_dist and not args.no_stream_probe:
         runner.release_outputs()  # the output volumes go back to the allocator before the probe's 8 GiB
@@ -423,6 +471,7 @@ def main():
                                          % (world, runner.config.get("line_groups", 1)),
                                          "" if runner.config["spacing"] == [1.0, 1.0, 1.0]
                                          else ", spacing %s" % runner.config["spacing"]),
+                   "iir_fma": 1 if args.iir_fma else 0,
                    "const_lines": args.const_lines,
                    "const_lines_meaning": "0: every line is filtered (every voxel pays the full path); "
                                           "1 (library default): lines that are all 0 or all 1 are copied",
@@ -435,6 +484,9 @@ def main():
         "ms_per_step_with_constant_line_shortcut": round(shortcut_ms, 3) if shortcut_ms else None,
         "roofline": roofline,
     }
+    if relaxed is not None:
+        out["relaxed"] = relaxed
+        out["headline"] = False
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth, seed, sigmas, args.cpu_sample)

@@ -308,12 +308,10 @@ class SlabEngine:
                  scales_per_item=None):
         """alloc(shape, dtype_name) -> tensor ('float32' or 'uint8') on the compute device;
         bounds: W+1 plane indices (default: slab_bounds); line_groups: items per scale group on
-        the boundary chains (default 4 up to four ranks, 3 beyond); scales_per_item: scales whose
-        sweeps share a launch and a message (default: all of them up to four ranks -- the jobs of
-        a launch share their input through L2 and the 64-plane launches of one scale leave most of
-        the device idle: 512^3 on a 128-plane slab 3.13 ms per step against 3.61 -- else one, so
-        that with eight ranks, where the 75 MB per boundary take longer than the local work, the
-        first scale leaves the chains early and computes while the others travel);
+        the boundary chains (default 4); scales_per_item: scales whose sweeps share a launch and a
+        message (default: all of them, up to the four a launch takes -- the jobs of a launch share
+        their input through L2 and the 64-plane launches of one scale leave most of the device
+        idle: 512^3 on a 64-plane slab 1.39 ms per step against 1.43 with one scale per item);
         streams: a _Streams (GPU)."""
         nz, ny, nx = shape_zyx
         self.bounds = list(bounds) if bounds is not None else slab_bounds(nz, world)
@@ -334,17 +332,20 @@ class SlabEngine:
         S = len(self.sigmas)
         L = ny * nx
         # line groups pipeline a boundary: the transfer of one group travels while the next is
-        # swept, and a chain's start-up (W-1 hops of sweep + wire + latency) shrinks with the item.
-        # Up to four ranks an item carries all scales, four groups.  At eight, one scale per item
-        # and three groups: 5.6 MB per item at 512^2 -- at the 60-75 GB/s a direction of an xGMI
-        # link carries, 7 hops of (16 + 80 + 30) us; two groups would start 0.4 ms later, four cost
-        # a third more point-to-point calls per step on a host thread that must stay ahead
-        G = line_groups if line_groups is not None else (1 if world == 1 else 4 if world <= 4 else 3)
+        # swept, and a chain's start-up (W-1 hops of kernel + wire + latency) shrinks with the
+        # item.  Four groups carrying all scales at every world size: with 50 MB per boundary and
+        # direction (512^2, 3 scales, 2 fields) an item is 12.6 MB, a chain of eight ranks takes
+        # 7 x (0.18 ms of wire at 70 GB/s + kernel + latency) + 3 x 0.18 = 2.4 ms from its first
+        # sweep to its last state -- hidden behind the two steps the engine keeps in flight -- at
+        # 16 point-to-point calls and 8 chain launches per rank and step.  (Round 2 ran eight
+        # ranks with one scale per item and three groups, 36 calls: the host thread then needs
+        # about as long per step as the device, scripts/experiments/slab_p2p_host_time.py.)
+        G = line_groups if line_groups is not None else (1 if world == 1 else 4)
         G = max(1, min(G, (L + 255) // 256))
         per = ((L + G - 1) // G + 255) // 256 * 256  # whole workgroups of 256 lines
         self.groups = [(l0, min(L, l0 + per) - l0) for l0 in range(0, L, per)]
         max_jobs = max(1, 8 // nf)                     # jobs of one launch (IIR_MAX_JOBS = 8)
-        spi = scales_per_item if scales_per_item else (S if world <= 4 else 1)
+        spi = scales_per_item if scales_per_item else S
         spi = max(1, min(spi, max_jobs, S))
         # scale groups: their sweeps share launches and messages; the bulk phase follows them
         self.scale_groups = [list(range(s0, min(S, s0 + spi))) for s0 in range(0, S, spi)]

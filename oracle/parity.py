@@ -10,6 +10,8 @@ therefore measured on the triples sorted by VALUE -- any real error shows there 
 requirement that each side is magnitude-ordered; voxels whose order differs are counted and
 reported.  All errors are relative to |lambda_1| of the reference (north_star: 1e-5).
 """
+import itertools
+
 import numpy as np
 
 
@@ -65,14 +67,17 @@ def eig_parity(got, ref, block=1 << 22, tie_tol=4e-6):
         out["near_ties"] += int((gap <= tie_tol).sum())
         if swapped.any():
             out["order_max_elem_err"] = max(out["order_max_elem_err"], float(de[swapped].max()))
+            # which positions changed hands: the permutation of the reference triple that the
+            # device triple matches best (identity first, so an exact fit is never "moved")
             rs_, gs_ = r[swapped, :3], g[swapped, :3]
-            moved = np.abs(gs_ - rs_) > se[swapped, None] * lam[swapped, None]   # the positions that changed hands
-            vals = np.where(moved, rs_, np.nan)
-            opp = (np.nanmin(vals, -1) < 0) & (np.nanmax(vals, -1) > 0)
-            out["order_opposite_sign"] += int(opp.sum())
-            mags = np.where(moved, np.abs(rs_), np.nan)
-            out["order_max_tie_gap"] = max(out["order_max_tie_gap"],
-                                           float(((np.nanmax(mags, -1) - np.nanmin(mags, -1)) / lam[swapped]).max()))
+            perms = np.array(list(itertools.permutations(range(3))))          # (6, 3)
+            errs = np.abs(gs_[:, None, :] - rs_[:, perms]).max(-1)             # (m, 6)
+            best = perms[np.argmin(errs, 1)]                                   # (m, 3)
+            partner = np.take_along_axis(rs_, best, 1)                         # reference value now at each position
+            moved = best != np.arange(3)[None, :]
+            out["order_opposite_sign"] += int((moved & (rs_ * partner < 0)).any(-1).sum())
+            gap = np.where(moved, np.abs(np.abs(rs_) - np.abs(partner)), 0.0).max(-1) / lam[swapped]
+            out["order_max_tie_gap"] = max(out["order_max_tie_gap"], float(gap.max()))
         a = np.abs(g[:, :3])
         slack = np.maximum(np.maximum(a[:, 1] - a[:, 0], a[:, 2] - a[:, 1]), 0.0) / lam
         out["mag_slack"] = max(out["mag_slack"], float(slack.max()))

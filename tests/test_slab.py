@@ -175,7 +175,8 @@ class OracleStages:
         out.copy_(torch.from_numpy(res))
 
 
-def _worker(rank, world, port, shape, sigmas, spacing, use_hip, bounds, line_groups, steps, spi, edge_groups, ret):
+def _worker(rank, world, port, shape, sigmas, spacing, use_hip, bounds, line_groups, steps, spi, edge_groups, ret,
+            i16=False):
     sys.path.insert(0, ROOT)
     os.environ["IFE_TRIG_MODE"] = "0"
     import torch
@@ -191,9 +192,9 @@ def _worker(rank, world, port, shape, sigmas, spacing, use_hip, bounds, line_gro
         b = bounds or slab.slab_bounds(nz, world)
         z0, nzl = b[rank], b[rank + 1] - b[rank]
         lo, hi = slab.overlap(rank, world)  # the raw slab with the neighbours' adjacent planes
-        img = synth.volume_f32((lo + nzl + hi, ny, nx), 77, z0=z0 - lo)
+        img = (synth.volume_i16 if i16 else synth.volume_f32)((lo + nzl + hi, ny, nx), 77, z0=z0 - lo)
         mask = np.minimum(synth.mask_ellipsoids((lo + nzl + hi, ny, nx), z0=z0 - lo, nz_total=nz), 1)
-        mask = mask.astype(np.uint8)
+        mask = mask.astype(np.uint16 if i16 else np.uint8)
         mask[:, :2, :] = 1
         streams = None
         if use_hip:
@@ -231,18 +232,18 @@ def _worker(rank, world, port, shape, sigmas, spacing, use_hip, bounds, line_gro
 
 
 def _run_world(world, shape, sigmas, spacing, use_hip, tmp_path, bounds=None, line_groups=None,
-               steps=1, spi=None, edge_groups=True):
+               steps=1, spi=None, edge_groups=True, i16=False):
     import torch.multiprocessing as mp
     port = _free_port()
     mp.spawn(_worker, args=(world, port, shape, sigmas, spacing, use_hip, bounds, line_groups,
-                            steps, spi, edge_groups, str(tmp_path)), nprocs=world, join=True)
+                            steps, spi, edge_groups, str(tmp_path), i16), nprocs=world, join=True)
     parts = [np.load(os.path.join(str(tmp_path), "out_%d.npy" % r)) for r in range(world)]
     return np.concatenate(parts, axis=1)  # along z
 
 
-def _whole_volume(synth, shape):
-    img = synth.volume_f32(shape, 77)
-    mask = np.minimum(synth.mask_ellipsoids(shape), 1).astype(np.uint8)
+def _whole_volume(synth, shape, i16=False):
+    img = (synth.volume_i16 if i16 else synth.volume_f32)(shape, 77)
+    mask = np.minimum(synth.mask_ellipsoids(shape), 1).astype(np.uint16 if i16 else np.uint8)
     mask[:, :2, :] = 1
     return img, mask
 
@@ -302,13 +303,18 @@ def test_slab_engine_rejects_thin_slabs(ife):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,shape,groups", [(2, (128, 512, 512), 2), (4, (45, 96, 200), 3)])
-def test_slab_engine_on_gpu_equals_single_gpu(ife, synth, tmp_path, world, shape, groups):
+@pytest.mark.parametrize("world,shape,groups,spacing,i16,sigmas", [
+    (2, (128, 512, 512), 2, (1.0, 1.0, 1.0), False, [1.0, 3.0, 2.0]),
+    (4, (45, 96, 200), 3, (1.0, 1.0, 1.0), False, [1.0, 3.0, 2.0]),
+    # BASELINE configs[4] in small: int16 CT-like input, uint16 labels, spacing 0.7 / 0.7 / 1.0,
+    # five scales (two scale groups at this world size), uneven slabs
+    (4, (50, 96, 132), 2, (0.7, 0.7, 1.0), True, [1.0, 2.0, 3.0, 4.0, 6.0]),
+])
+def test_slab_engine_on_gpu_equals_single_gpu(ife, synth, tmp_path, world, shape, groups, spacing, i16, sigmas):
     """HIP stages, two streams per rank, ranks sharing the one GPU: bit-identical to the
     single-GPU path (which is itself compared with the oracle elsewhere)."""
-    sigmas, spacing = [1.0, 3.0, 2.0], (1.0, 1.0, 1.0)
-    got = _run_world(world, shape, sigmas, spacing, True, tmp_path, None, groups, 3)
-    img, mask = _whole_volume(synth, shape)
+    got = _run_world(world, shape, sigmas, spacing, True, tmp_path, None, groups, 3, i16=i16)
+    img, mask = _whole_volume(synth, shape, i16)
     with ife.Context(0) as c:
         c.set_option(ife.OPT_TRIG_MODE, 0)
         ref = c.emphysema_features(img, mask, sigmas, spacing)
