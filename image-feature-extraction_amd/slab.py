@@ -522,7 +522,9 @@ class SlabRunner:
         self.d_out = torch.empty(oshape, dtype=torch.float32, device=dev)
         # the one-rank form (bench.py --force-slab: a rank's local work without neighbours) keeps
         # the two streams of a real rank
-        self.streams = _Streams(torch, dev, two_streams=world > 1 or bool(getattr(args, "force_slab", False)))
+        import os
+        two = (world > 1 or bool(getattr(args, "force_slab", False))) and not os.environ.get("IFE_SLAB_ONE_STREAM")
+        self.streams = _Streams(torch, dev, two_streams=two)  # IFE_SLAB_ONE_STREAM: diagnostics (clean per-kernel times)
         self.ctx = pkg.Context(dev.index or 0)
         self.ctx.set_stream(self.streams.bulk.cuda_stream)
         self.chain_ctx = self.ctx
