@@ -460,6 +460,41 @@ def test_bad_arguments(ctx, ife):
         ctx.set_option(999, 1)
 
 
+def test_new_entry_points_refuse_bad_arguments(ctx, ife):
+    """Round-3 additions to the C-ABI: argument checks happen on the host, before any launch."""
+    import torch
+    a = torch.zeros(1 << 20, dtype=torch.float32, device="cuda")
+    b = torch.zeros(1 << 20, dtype=torch.float32, device="cuda")
+    gbs = ctx.measure_stream(1, b.data_ptr(), a.data_ptr(), a.numel() * 4, 2)
+    assert gbs > 10.0
+    assert ctx.measure_stream(0, b.data_ptr(), None, a.numel() * 4, 2) > 10.0
+    for args in ((1, b.data_ptr(), None, 4096, 1),          # a copy needs a source
+                 (0, b.data_ptr() + 4, None, 4096, 1),      # 16-byte alignment
+                 (0, b.data_ptr(), None, 4100, 1),          # whole 16-byte pieces
+                 (2, b.data_ptr(), a.data_ptr(), 4096, 1),  # unknown mode
+                 (0, b.data_ptr(), None, 4096, 0)):         # at least one pass
+        with pytest.raises(ife.IfeError) as e:
+            ctx.measure_stream(*args)
+        assert e.value.code == ife.E_ARG
+    shape = (8, 8, 64)
+    vol = torch.zeros(shape, dtype=torch.float32, device="cuda")
+    out = torch.zeros(shape, dtype=torch.float32, device="cuda")
+    ck = torch.zeros(ctx.stage_z_ck_bytes(shape), dtype=torch.uint8, device="cuda")
+    st = torch.zeros(ife.Z_STATE_BYTES * 64 * 8, dtype=torch.uint8, device="cuda")
+    with pytest.raises(ife.IfeError) as e:   # a neighbour below, but no incoming state
+        ctx.stage_z_fused(0, [vol.data_ptr()], [out.data_ptr()], shape, (1, 1, 1), 0, 512, [1.0], True, False,
+                          None, st.data_ptr(), [ck.data_ptr()])
+    assert e.value.code == ife.E_ARG
+    with pytest.raises(ife.IfeError) as e:   # in place
+        ctx.stage_z_fused(1, [vol.data_ptr()], [vol.data_ptr()], shape, (1, 1, 1), 0, 512, [1.0], False, False,
+                          None, st.data_ptr(), [ck.data_ptr()])
+    assert e.value.code == ife.E_ARG
+    with pytest.raises(ife.IfeError) as e:   # the quotient form runs on the strided axes only
+        ctx.stage_recursive_gaussian_quotient([vol.data_ptr()], [vol.data_ptr()], [out.data_ptr()], shape,
+                                              (1, 1, 1), 0, [1.0])
+    assert e.value.code == ife.E_ARG
+
+
 # ---------------------------------------------------------------------------------
 # self-pinned golden files (tests/golden/make_golden.py)
 # ---------------------------------------------------------------------------------
