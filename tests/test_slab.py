@@ -254,6 +254,8 @@ def _whole_volume(synth, shape, i16=False):
     (4, (29, 24, 40), (0.8, 1.0, 1.25), None, 2, 3, 1, True),            # 8,7,7,7 planes, one scale per item; three steps: both buffer sets reused
     (4, (16, 20, 24), (1.0, 1.0, 1.0), None, 2, 2, 1, False),            # everything on the default group
     (8, (37, 16, 40), (1.0, 1.0, 1.0), None, None, 2, None, True),       # eight ranks, the engine's own defaults there
+    (5, (23, 16, 24), (1.0, 1.0, 1.0), [0, 4, 8, 13, 19, 23], 2, 2, None, True),  # odd world: the middle rank's directions tie
+    (6, (30, 12, 40), (1.2, 0.9, 1.0), None, 3, 2, 1, True),             # lean causal on ranks 0-2, lean anticausal on 3-5
 ])
 def test_slab_engine_equals_single_process_oracle(oracle, synth, tmp_path, world, shape, spacing,
                                                   bounds, groups, steps, spi, edge_groups):
