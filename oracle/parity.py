@@ -43,7 +43,8 @@ def eig_parity(got, ref, block=1 << 22, tie_tol=4e-6):
     r2 = ref.reshape(-1, C)
     out = {"max_err": 0.0, "order_diff": 0, "mag_slack": 0.0, "n": 0,
            "max_err_sum": 0.0, "max_err_frob": 0.0, "max_err_prod": 0.0,
-           "order_max_elem_err": 0.0, "order_opposite_sign": 0, "order_max_tie_gap": 0.0, "near_ties": 0}
+           "order_max_elem_err": 0.0, "order_opposite_sign": 0, "order_max_tie_gap": 0.0, "near_ties": 0,
+           "nonfinite": 0}
     for i in range(0, g2.shape[0], block):
         g = g2[i:i + block, e0:].astype(np.float64)
         r = r2[i:i + block, e0:].astype(np.float64)
@@ -53,6 +54,13 @@ def eig_parity(got, ref, block=1 << 22, tie_tol=4e-6):
             if np.isfinite(g[~ok, :3]).all(-1).any():
                 out["max_err"] = float("inf")
             g, r = g[ok], r[ok]
+        # ... and a finite reference triple must be finite on the device: a NaN would otherwise
+        # drop out of every max() below (max(x, nan) keeps x) and pass unseen
+        gbad = ~np.isfinite(g[:, :3]).all(-1)
+        if gbad.any():
+            out["nonfinite"] += int(gbad.sum())
+            out["max_err"] = float("inf")
+            g, r = g[~gbad], r[~gbad]
         if g.shape[0] == 0:
             continue
         lam = np.maximum(np.abs(r[:, 0]), 1e-30)
@@ -83,13 +91,27 @@ def eig_parity(got, ref, block=1 << 22, tie_tol=4e-6):
         out["mag_slack"] = max(out["mag_slack"], float(slack.max()))
         out["n"] += g.shape[0]
         if g.shape[1] >= 6:
-            out["max_err_sum"] = max(out["max_err_sum"], float((np.abs(g[:, 3] - r[:, 3]) / lam).max()))
+            # derived scalars: where the reference overflowed (a float32 product or sum of
+            # squares can) the device must show the same non-finite value; elsewhere the error
+            # is relative, and a non-finite device value is an infinite error
+            def derived(k, slack=0.0):
+                fin = np.isfinite(r[:, k])
+                same = np.where(fin, True, (g[:, k] == r[:, k]) | (np.isnan(g[:, k]) & np.isnan(r[:, k])))
+                if not same.all() or not np.isfinite(g[fin, k]).all():
+                    return None, fin
+                return np.maximum(np.abs(g[fin, k] - r[fin, k]) - slack, 0.0), fin
+            d, fin = derived(3)
+            out["max_err_sum"] = float("inf") if d is None else max(out["max_err_sum"], float((d / lam[fin]).max(initial=0.0)))
             # the product of three tiny eigenvalues lands among the float32 denormals, where one
             # unit in the last place (1.4e-45) is no longer small against lambda_1^3: two such
             # units are allowed before the relative bar applies
-            dp = np.maximum(np.abs(g[:, 4] - r[:, 4]) - 2.0 * 1.4012984643e-45, 0.0)
-            out["max_err_prod"] = max(out["max_err_prod"], float((dp / lam ** 3).max()))
-            out["max_err_frob"] = max(out["max_err_frob"], float((np.abs(g[:, 5] - r[:, 5]) / lam).max()))
+            d, fin = derived(4, 2.0 * 1.4012984643e-45)
+            out["max_err_prod"] = float("inf") if d is None else max(out["max_err_prod"], float((d / lam[fin] ** 3).max(initial=0.0)))
+            d, fin = derived(5)
+            out["max_err_frob"] = float("inf") if d is None else max(out["max_err_frob"], float((d / lam[fin]).max(initial=0.0)))
+    for k, v in out.items():  # nothing may have slipped through as NaN
+        if isinstance(v, float) and v != v:
+            out[k] = float("inf")
     return out
 
 

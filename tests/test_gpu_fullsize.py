@@ -200,3 +200,49 @@ def test_config5_like_int16_five_scales_matches_oracle(ife, oracle, synth):
         d = np.abs(got[s][..., 2:].astype(np.float64) - ref[..., 2:])
         assert (d[..., 0:4] / lam[..., None]).max() <= 1e-6
         assert (d[..., 5] / lam).max() <= 1e-6
+
+
+@pytest.mark.skipif(os.environ.get("IFE_FULL_CONFIG5") not in ("0", "2"),
+                    reason="BASELINE configs[4] at its full size: ~15 min and ~70 GB of host memory per trig "
+                           "mode; set IFE_FULL_CONFIG5=2 (the library's default mode) or =0 (double "
+                           "evaluation).  Results of the last runs: DESIGN.md section 2")
+def test_config5_full_size_matches_oracle(ife, oracle, synth):
+    """BASELINE configs[4] at its FULL size on one GPU: 1024 x 1024 x 768 int16, label mask
+    clamped to {0,1}, spacing 0.7 x 0.7 x 1.0, sigma = 1, 2, 3, 4, 6 -- every voxel of every
+    scale against the oracle.  One upload and one prepass for the five scales
+    (ife_emphysema_features_begin), one scale fetched and checked at a time.  Same bars as
+    the 512^3 test: smoothed value and gradient magnitude bit exact; eigen features <= 2e-6
+    |lambda_1| in the default float mode, <= 1e-6 and no order difference in mode 0."""
+    from oracle.parity import assert_eig_parity
+    mode = int(os.environ["IFE_FULL_CONFIG5"])
+    tol = 2e-6 if mode == 2 else 1e-6
+    shape = (768, 1024, 1024)
+    spacing = (0.7, 0.7, 1.0)
+    sigmas = [1.0, 2.0, 3.0, 4.0, 6.0]
+    img = synth.volume_i16(shape, synth.SEED_CONFIG[5])
+    mask = np.empty(shape, np.uint8)
+    for z in range(0, shape[0], 64):  # slab by slab: the generator's temporaries are int64
+        mask[z:z + 64] = np.minimum(synth.mask_ellipsoids((min(64, shape[0] - z),) + shape[1:], z0=z,
+                                                          nz_total=shape[0]), 1)
+    imgf = img.astype(np.float32)
+    oracle.set_threads(min(16, os.cpu_count() or 1))
+    nvox = int(np.prod(shape))
+    with ife.Context(0) as c:
+        c.set_option(ife.OPT_TRIG_MODE, mode)  # the test session's contexts start in mode 0 (conftest.py)
+        for s, got in enumerate(c.emphysema_features_stream(img, mask, sigmas, spacing)):
+            ref = oracle.emphysema_features(imgf, mask, sigmas[s], spacing)
+            assert np.array_equal(got[..., 0], ref[..., 0]), "smoothed value, sigma %g" % sigmas[s]
+            assert np.array_equal(got[..., 1], ref[..., 1]), "gradient magnitude, sigma %g" % sigmas[s]
+            # the order allowance of the 512^3 test (16 per 1.34e8 triples), scaled to this volume
+            p = assert_eig_parity(got, ref, tol, "config 5, sigma %g" % sigmas[s],
+                                  max_order=16 * nvox // (512 ** 3) if mode == 2 else 0)
+            for z in range(0, shape[0], 64):
+                assert (got[z:z + 64][mask[z:z + 64] == 0] == 0).all()
+            print("1024x1024x768 int16 sigma %g trig mode %d: S and G bit exact, max eigenvalue error %.3g "
+                  "|lambda1| (sum %.3g, Frobenius %.3g, product %.3g |lambda1|^3), %d of %d triples in another "
+                  "order (widest swapped pair %.3g |lambda1| apart), bit-identical components %.6f"
+                  % (sigmas[s], mode, p["max_err"], p["max_err_sum"], p["max_err_frob"], p["max_err_prod"],
+                     p["order_diff"], p["n"], p["order_max_tie_gap"],
+                     float(np.mean([(got[z:z + 64] == ref[z:z + 64]).mean() for z in range(0, shape[0], 64)]))),
+                  flush=True)
+            del got, ref
