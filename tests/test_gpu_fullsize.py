@@ -229,7 +229,10 @@ def test_config5_full_size_matches_oracle(ife, oracle, synth):
     nvox = int(np.prod(shape))
     with ife.Context(0) as c:
         c.set_option(ife.OPT_TRIG_MODE, mode)  # the test session's contexts start in mode 0 (conftest.py)
+        first = int(os.environ.get("IFE_FULL_CONFIG5_FROM", "0"))  # a scale costs ~4 min of checking: a run may start late
         for s, got in enumerate(c.emphysema_features_stream(img, mask, sigmas, spacing)):
+            if s < first:
+                continue
             ref = oracle.emphysema_features(imgf, mask, sigmas[s], spacing)
             assert np.array_equal(got[..., 0], ref[..., 0]), "smoothed value, sigma %g" % sigmas[s]
             assert np.array_equal(got[..., 1], ref[..., 1]), "gradient magnitude, sigma %g" % sigmas[s]
