@@ -115,6 +115,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream-probe", action="store_true",
                     help="skip the 4-GiB fill / copy that measures the box's streaming rates")
+    ap.add_argument("--proxy-world", type=int, default=None,
+                    help="timing proxy (implies --force-slab, never a headline): this one GPU runs the "
+                         "LOCAL work of rank --proxy-rank of this many Z-slabs of --size, transfers left "
+                         "out (slab.NullComm); `value` is then the whole volume over this rank's step")
+    ap.add_argument("--proxy-rank", type=int, default=0)
     ap.add_argument("--force-slab", action="store_true",
                     help="run the Z-slab engine (RCCL exchanges) even with one rank")
     ap.add_argument("--cpu-sample", type=int, default=512, help="edge of the CPU baseline cube")
@@ -127,7 +132,12 @@ def parse():
                          "sum and rank 0 prints a stub line (tests/test_bench_launch.py)")
     ap.add_argument("--launch-timeout", type=float, default=900.0,
                     help="self-launch: seconds after which the launcher ends its ranks")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.proxy_world:
+        if a.gpus != 1 or not 0 <= a.proxy_rank < a.proxy_world:
+            ap.error("--proxy-world needs --gpus 1 and 0 <= --proxy-rank < --proxy-world")
+        a.force_slab = True
+    return a
 
 
 def launch_ranks(args):
@@ -385,6 +395,7 @@ def main():
         dt = float(tmax.item())
 
     nvox = nz * ny * nx
+    share = args.proxy_world or world  # slabs the volume is cut into (this rank's work: nvox / share)
     t_step = dt / args.steps
     value = nvox * len(sigmas) / t_step / 1e6
 
@@ -411,7 +422,7 @@ def main():
         if name in alg:
             # units of work per step: field passes for the line kernels, scales for the rest
             units = {"prep": 1, "features": len(sigmas)}.get(name, len(sigmas) * nfields)
-            gbs = alg[name] * units * (nvox / world) / (per_step_ms * 1e-3) / 1e9
+            gbs = alg[name] * units * (nvox / share) / (per_step_ms * 1e-3) / 1e9
             e["alg_bytes_per_voxel"] = alg[name]
             e["units_per_step"] = units
             e["achieved_GBs"] = round(gbs, 1)
@@ -422,7 +433,7 @@ def main():
             e["issue_floor_ms"] = round(floor, 4)  # per launch, like avg_ms
             issue_floor_step += floor * n / args.steps
         kern[name] = e
-    alg_bytes_step_rank = ALG_BYTES_PER_VOXEL_SCALE * (nvox / world) * len(sigmas)
+    alg_bytes_step_rank = ALG_BYTES_PER_VOXEL_SCALE * (nvox / share) * len(sigmas)
     # one GPU: the kernels of a step run back to back, their hipEvent durations add up to the
     # device time.  Slab engine: two streams per rank and successive steps overlap, so the sum
     # exceeds the step; the step's wall time is the denominator there
@@ -468,7 +479,7 @@ def main():
                                          args.layout,
                                          "1 GPU" if not use_dist else
                                          "%d Z-slabs, boundary-state hand-off, %d line groups per scale"
-                                         % (world, runner.config.get("line_groups", 1)),
+                                         % (share, runner.config.get("line_groups", 1)),
                                          "" if runner.config["spacing"] == [1.0, 1.0, 1.0]
                                          else ", spacing %s" % runner.config["spacing"]),
                    "iir_fma": 1 if args.iir_fma else 0,
@@ -487,6 +498,12 @@ def main():
     if relaxed is not None:
         out["relaxed"] = relaxed
         out["headline"] = False
+    if args.proxy_world:
+        out["headline"] = False
+        out["config"]["proxy"] = ("timing proxy: the local work of rank %d of %d Z-slabs on one GPU, transfers "
+                                  "left out, state buffers zero -- `value` = the whole volume over this rank's "
+                                  "step, an upper bound on what %d such GPUs could reach"
+                                  % (args.proxy_rank, args.proxy_world, args.proxy_world))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth, seed, sigmas, args.cpu_sample)

@@ -580,7 +580,10 @@ int launch_iir(ife_ctx *ctx, const ife_volume_desc *v, int axis, int njobs,
 }
 
 // ---- Z pass of a Z-slab (iir_types.hpp "ZSlabJob") -----------------------------------
-constexpr int ZSLAB_K = 12;  // register block of the slab kernels (fixes the checkpoint layout)
+#ifndef IFE_ZSLAB_K
+#define IFE_ZSLAB_K 12
+#endif
+constexpr int ZSLAB_K = IFE_ZSLAB_K;  // register block of the slab kernels (fixes the checkpoint layout)
 int64_t zslab_pairs(int64_t n) { return ((n + ZSLAB_K - 1) / ZSLAB_K + 1) / 2; }
 size_t zslab_ck_bytes(const ife_volume_desc *v) {
   const size_t L = (size_t)(v->nx * v->ny);

@@ -275,6 +275,21 @@ class TorchComm:
             dst.copy_(src)
 
 
+class NullComm:
+    """Timing proxy only (bench.py --proxy-rank): the interface of TorchComm with every transfer
+    left out, so that ONE GPU can run the local work of rank r of W -- neighbours on the sides
+    that rank has, hence the interior forms of the Z kernels and the halo planes of the feature
+    pass -- on whatever the state buffers hold.  The numbers it produces mean nothing."""
+
+    def isend_up(self, buf):
+        return _Xfer(None)
+
+    irecv_up = isend_down = irecv_down = isend_up
+
+    def halo(self, first_planes, last_planes, lo_halos, hi_halos):
+        pass
+
+
 class _Streams:
     """Two HIP streams on a GPU (boundary sweeps ahead of bulk kernels) or nothing on CPU."""
 
@@ -502,6 +517,9 @@ class SlabRunner:
     def __init__(self, pkg, synth, shape, sigmas, seed, mask_kind, layout, rank, world, dev, args):
         import torch
         import torch.distributed as dist
+        proxy = getattr(args, "proxy_world", None)
+        if proxy:  # one GPU standing in for rank `proxy_rank` of `proxy_world`: local work only
+            rank, world = int(getattr(args, "proxy_rank", 0) or 0), int(proxy)
         nz, ny, nx = shape
         bounds = slab_bounds(nz, world)
         z0, nzl = bounds[rank], bounds[rank + 1] - bounds[rank]
@@ -524,6 +542,7 @@ class SlabRunner:
         # the two streams of a real rank
         import os
         two = (world > 1 or bool(getattr(args, "force_slab", False))) and not os.environ.get("IFE_SLAB_ONE_STREAM")
+        comm = NullComm() if proxy else TorchComm(dist, rank, world, device=dev)
         self.streams = _Streams(torch, dev, two_streams=two)  # IFE_SLAB_ONE_STREAM: diagnostics (clean per-kernel times)
         self.ctx = pkg.Context(dev.index or 0)
         self.ctx.set_stream(self.streams.bulk.cuda_stream)
@@ -545,12 +564,15 @@ class SlabRunner:
         dt = {"float32": torch.float32, "uint8": torch.uint8}
         alloc = lambda shp, d: torch.empty(shp, dtype=dt[d], device=dev)
         self.engine = SlabEngine(HipStages(pkg, self.ctx, self.chain_ctx),
-                                 TorchComm(dist, rank, world, device=dev), shape, spacing, sigmas, rank, world,
+                                 comm, shape, spacing, sigmas, rank, world,
                                  alloc, layout, has_mask=self.d_mask is not None,
                                  streams=self.streams,
                                  line_groups=getattr(args, "line_groups", None),
                                  scales_per_item=getattr(args, "scales_per_item", None))
         # what was actually built, for the bench line
+        if proxy:  # the state buffers are never received into: give them finite contents
+            for b in self.engine.c_in + self.engine.a_in:
+                b.zero_()
         self.config = {"input": "int16" if i16 else "float32", "spacing": list(spacing),
                        "slab_planes": nzl, "line_groups": len(self.engine.groups),
                        "scales_per_item": len(self.engine.scale_groups[0])}

@@ -54,3 +54,13 @@ def test_slab_engine_line_with_one_rank():
     assert set(d["roofline"]["kernels"]) >= {"zslab_sweep", "zslab_combine", "iir_x", "iir_y", "features"}
     assert d["roofline"]["issue"] is None                      # PMC instruction counts exist only for the default workload
     assert "cpu_baseline" not in d
+
+
+def test_per_rank_timing_proxy_is_marked_as_such():
+    """--proxy-world: one GPU runs the local work of a rank with neighbours (no transfers);
+    the line must say that it is no headline."""
+    d = run_bench("--gpus", "1", "--steps", "1", "--warmup", "1", "--size", "64", "64", "64",
+                  "--proxy-world", "4", "--proxy-rank", "1", "--no-cpu-baseline")
+    assert d["headline"] is False and "rank 1 of 4" in d["config"]["proxy"]
+    assert "4 Z-slabs" in d["config"]["workload"] and d["n_gpus"] == 1
+    assert set(d["roofline"]["kernels"]) >= {"zslab_sweep", "zslab_combine", "iir_x", "iir_y", "features"}
