@@ -120,6 +120,9 @@ def parse():
                          "LOCAL work of rank --proxy-rank of this many Z-slabs of --size, transfers left "
                          "out (slab.NullComm); `value` is then the whole volume over this rank's step")
     ap.add_argument("--proxy-rank", type=int, default=0)
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="diagnostic: leave the per-kernel hipEvents out of the timed region (no kernel "
+                         "table, no roofline.achieved from device time)")
     ap.add_argument("--force-slab", action="store_true",
                     help="run the Z-slab engine (RCCL exchanges) even with one rank")
     ap.add_argument("--cpu-sample", type=int, default=512, help="edge of the CPU baseline cube")
@@ -352,8 +355,14 @@ def main():
 
     for _ in range(args.warmup):
         runner.step()
+    # Per-kernel hipEvents (two records per launch).  One GPU: inside the timed region -- eight
+    # launches of 0.3-2 ms per step, the records cost nothing measurable (8.86 vs 8.88 ms).  Slab
+    # engine: ~26 launches of 20-60 us per step on two streams, where the records cost 2.7 % of
+    # the step (scripts/experiments/r3_events_cost.sh: 1.367 -> 1.330 ms); there the K timed
+    # steps run without them and the kernel table comes from extra steps behind the timed region.
+    events_in_timed = not use_dist and not args.no_kernel_events
     for c in runner.contexts():
-        c.set_option(pkg.OPT_PROFILE, 1)
+        c.set_option(pkg.OPT_PROFILE, 1 if events_in_timed else 0)
         c.reset_kernel_times()
     barrier()
     torch.cuda.synchronize()
@@ -363,6 +372,16 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    ksteps = args.steps  # steps the kernel table below is summed over
+    if use_dist and not args.no_kernel_events:
+        ksteps = min(args.steps, 5)
+        for c in runner.contexts():
+            c.set_option(pkg.OPT_PROFILE, 1)
+            c.reset_kernel_times()
+        for _ in range(ksteps):
+            runner.step()
+        torch.cuda.synchronize()
+        barrier()
     ktimes = {}
     for c in runner.contexts():
         for name, (n, ms) in c.kernel_times().items():
@@ -415,9 +434,9 @@ def main():
     issue_floor_step = 0.0
     nfields = 1 if args.mask == "none" else 2
     for name, (n, ms) in ktimes.items():
-        per_step_ms = ms / args.steps
+        per_step_ms = ms / ksteps
         dev_ms_step += per_step_ms
-        e = {"launches_per_step": n / args.steps, "avg_ms": round(ms / n, 4),
+        e = {"launches_per_step": n / ksteps, "avg_ms": round(ms / n, 4),
              "ms_per_step": round(per_step_ms, 4)}
         if name in alg:
             # units of work per step: field passes for the line kernels, scales for the rest
@@ -431,7 +450,7 @@ def main():
             floor = prof_kinds[name]["valu_insts"] * 4.0 / (SIMDS * SUSTAINED_GHZ * 1e9) * 1e3
             e["valu_insts_per_launch"] = prof_kinds[name]["valu_insts"]
             e["issue_floor_ms"] = round(floor, 4)  # per launch, like avg_ms
-            issue_floor_step += floor * n / args.steps
+            issue_floor_step += floor * n / ksteps
         kern[name] = e
     alg_bytes_step_rank = ALG_BYTES_PER_VOXEL_SCALE * (nvox / share) * len(sigmas)
     # one GPU: the kernels of a step run back to back, their hipEvent durations add up to the
@@ -460,8 +479,9 @@ def main():
                 if traffic else None,
                 "issue": issue,
                 "scope": ("this rank's share of one step over the step's wall time (%.3f ms; the kernels "
-                          "of its two streams overlap: their hipEvent durations sum to %.3f ms); "
-                          % (scope_ms, dev_ms_step) if use_dist else
+                          "of its two streams overlap: their hipEvent durations, taken over %d extra steps "
+                          "behind the timed region, sum to %.3f ms); "
+                          % (scope_ms, ksteps, dev_ms_step) if use_dist else
                           "all kernels of one step (sum of hipEvent durations %.3f ms); " % dev_ms_step)
                          + "algorithmic bytes = 37 B x voxels x scales",
                 "dominant_kernel": dominant, "kernels": kern}
