@@ -324,6 +324,25 @@ def test_slab_engine_on_gpu_equals_single_gpu(ife, synth, tmp_path, world, shape
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(not os.environ.get("IFE_FULL_SLAB"),
+                    reason="BASELINE configs[3] at its full size through the engine: four ranks sharing the "
+                           "one GPU, ~26 GB of outputs through host memory and the temporary directory; set "
+                           "IFE_FULL_SLAB=1 (result of the last run: DESIGN.md section 6)")
+def test_slab_engine_full_size_equals_single_gpu(ife, synth, tmp_path):
+    """512^3, sigma = 1, 2, 4 cut into the four 128-plane slabs of configs[3] at N = 4, the
+    engine's defaults (four line groups, all scales per item), two steps: every voxel of every
+    scale bit-identical to the single-device path."""
+    shape, sigmas, spacing = (512, 512, 512), [1.0, 2.0, 4.0], (1.0, 1.0, 1.0)
+    got = _run_world(4, shape, sigmas, spacing, True, tmp_path, None, None, 2)
+    img, mask = _whole_volume(synth, shape)
+    with ife.Context(0) as c:
+        c.set_option(ife.OPT_TRIG_MODE, 0)
+        for s, ref in enumerate(c.emphysema_features_stream(img, mask, sigmas, spacing)):
+            assert np.array_equal(got[s], ref), "scale %d differs from the single-device path" % s
+            del ref
+
+
+@pytest.mark.gpu
 def test_slab_engine_on_gpu_random_configurations(ife, synth, tmp_path):
     """The Python engine (what bench.py runs at N > 1) on drawn configurations: 2-5 ranks sharing
     the GPU, awkward shapes, uneven cuts, 1-5 line groups, one or all scales per item, two or
