@@ -24,13 +24,17 @@ Everything is slab-local except two things:
 Per step and rank (S scales, nf = 2 fields with a mask, G line groups per scale):
 
   prepare                       tc = image*mask, cf = float(mask)                (local)
-  chain stream, items (scale group q, line group g) in expected-arrival order:
-      the direction whose state reaches this rank FIRST (causal in the lower half of the
-      ranks, anticausal in the upper) as a lean sweep: [recv state] one recursion step per
-      sample, checkpoints [send state];
-      the other direction FUSED with the combine: [recv state] that recursion carried through
-      the slab, the first one rebuilt from its checkpoints, the Z output written [send state].
+  boundary chains, items (scale group q, line group g) in expected-arrival order:
+      chain stream: the direction whose state reaches this rank FIRST (causal in the lower half
+      of the ranks, anticausal in the upper) as a lean sweep: [recv state] one recursion step
+      per sample, checkpoints [send state];
+      fused stream: the other direction FUSED with the combine: [recv state] that recursion
+      carried through the slab, the first one rebuilt from its checkpoints, the Z output
+      written [send state].
       Three recursion steps per sample and rank (round 2: two sweeps and a combine, four).
+      Two streams, and `depth` sets of the per-step buffers: the fused sweeps of step t wait for
+      the state that arrives last, the lean sweeps of steps t+1 .. t+depth-1 start the next
+      chains meanwhile (_Streams).
   bulk stream, per scale group (all scales up to four ranks, else one scale):
       X pass, Y pass (stores numerator / denominator), halo exchange, features  (local)
 
@@ -80,10 +84,12 @@ def sweep_schedule(rank, world, n_items):
 
 class HipStages:
     """Stage calls through the C-ABI on torch device tensors.  `ctx` runs the bulk work,
-    `chain_ctx` (bound to another stream; may be the same context) the boundary sweeps."""
+    `chain_ctx` (bound to another stream; may be the same context) the prepass and the lean
+    boundary sweeps, `fused_ctx` (a third stream; default: chain_ctx) the fused sweeps."""
 
-    def __init__(self, pkg, ctx, chain_ctx=None):
+    def __init__(self, pkg, ctx, chain_ctx=None, fused_ctx=None):
         self.pkg, self.ctx, self.chain_ctx = pkg, ctx, chain_ctx or ctx
+        self.fused_ctx = fused_ctx or self.chain_ctx
 
     def ck_bytes(self, slab_shape):
         return self.ctx.stage_z_ck_bytes(slab_shape)
@@ -113,7 +119,7 @@ class HipStages:
         direction whose state arrives last; needs the other direction's checkpoints in cks."""
         own = [t[pad_lo:pad_lo + nzl] for t in srcs_ext]
         has_nb = has_lo if direction == 0 else has_hi
-        self.chain_ctx.stage_z_fused(direction, [t.data_ptr() for t in own], [t.data_ptr() for t in dsts],
+        self.fused_ctx.stage_z_fused(direction, [t.data_ptr() for t in own], [t.data_ptr() for t in dsts],
                                      tuple(own[0].shape), spacing, line0, nlines, sigmas, has_lo, has_hi,
                                      state_in.data_ptr() if has_nb else None, state_out.data_ptr(),
                                      [c.data_ptr() for c in cks])
@@ -172,6 +178,11 @@ class TorchComm:
         """device: where the exchanged buffers live (a torch.device for RCCL; None = host)."""
         self.dist, self.rank, self.world, self.host = dist, rank, world, host_staging
         self.up, self.down, self.halo_g = [], [], []
+        # False: all traffic of an edge shares one communicator.  The engine then keeps the lean
+        # and the fused sweeps in ONE stream: with a communicator per class the lean chain may
+        # run steps ahead of the fused one, on a shared one that reorders the two ranks' operations
+        # against each other and they block for good.
+        self.per_class = True
         try:
             if not per_edge_groups:
                 raise RuntimeError("disabled by the caller")
@@ -187,6 +198,7 @@ class TorchComm:
             print("slab.TorchComm: per-edge communicators unavailable (%s); using the default group"
                   % exc, file=sys.stderr)
             self.up = self.down = self.halo_g = [None] * max(world - 1, 0)
+            self.per_class = False
         self._handshake(device)
 
     def _handshake(self, device):
@@ -281,6 +293,8 @@ class NullComm:
     that rank has, hence the interior forms of the Z kernels and the halo planes of the feature
     pass -- on whatever the state buffers hold.  The numbers it produces mean nothing."""
 
+    per_class = True
+
     def isend_up(self, buf):
         return _Xfer(None)
 
@@ -291,13 +305,20 @@ class NullComm:
 
 
 class _Streams:
-    """Two HIP streams on a GPU (boundary sweeps ahead of bulk kernels) or nothing on CPU."""
+    """The HIP streams of a rank on a GPU, or nothing on CPU: `bulk` (X, Y, features), `chain`
+    (prepass and the lean sweeps), `fused` (the fused sweeps), `post` (receives are posted from
+    it).  The lean and the fused sweeps have streams of their own because the fused sweeps of
+    step t wait for the state that arrives LAST -- on the end ranks after W-1 hops -- and the lean
+    sweeps of step t+1, which START the next chain, must not queue behind that wait: in one
+    in-order stream the two end ranks would hand the chains back and forth and a step would take
+    a whole chain latency however little work it holds."""
 
     def __init__(self, torch, dev, two_streams):
         self.torch = torch
         self.gpu = dev is not None and dev.type == "cuda"
         self.bulk = torch.cuda.current_stream(dev) if self.gpu else None
         self.chain = (torch.cuda.Stream(dev, priority=-1) if two_streams else self.bulk) if self.gpu else None
+        self.fused = (torch.cuda.Stream(dev, priority=-1) if two_streams else self.bulk) if self.gpu else None
         self.post = torch.cuda.Stream(dev) if self.gpu and two_streams else self.bulk
 
     def on(self, stream):
@@ -320,14 +341,21 @@ class SlabEngine:
 
     def __init__(self, stages, comm, shape_zyx, spacing, sigmas, rank, world, alloc, layout,
                  has_mask=True, line_groups=None, bounds=None, streams=None,
-                 scales_per_item=None):
+                 scales_per_item=None, depth=3):
         """alloc(shape, dtype_name) -> tensor ('float32' or 'uint8') on the compute device;
         bounds: W+1 plane indices (default: slab_bounds); line_groups: items per scale group on
         the boundary chains (default 4); scales_per_item: scales whose sweeps share a launch and a
         message (default: all of them, up to the four a launch takes -- the jobs of a launch share
         their input through L2 and the 64-plane launches of one scale leave most of the device
         idle: 512^3 on a 64-plane slab 1.39 ms per step against 1.43 with one scale per item);
-        streams: a _Streams (GPU)."""
+        streams: a _Streams (GPU); depth: sets of the per-step buffers (samples with overlap,
+        checkpoints, Z output), i.e. how many steps the lean chain may run ahead of the bulk work:
+        the chain of a step needs W-1 hops from end to end, and with d sets a step can be as short
+        as that latency / d (eight ranks: ~2.4 ms predicted at 70 GB/s per link, 3.4 at 45; local
+        work 1.33 ms)."""
+        if depth < 2:
+            raise ValueError("depth must be at least 2")
+        self.depth = int(depth)
         nz, ny, nx = shape_zyx
         self.bounds = list(bounds) if bounds is not None else slab_bounds(nz, world)
         if len(self.bounds) != world + 1 or self.bounds[0] != 0 or self.bounds[-1] != nz:
@@ -351,7 +379,7 @@ class SlabEngine:
         # item.  Four groups carrying all scales at every world size: with 50 MB per boundary and
         # direction (512^2, 3 scales, 2 fields) an item is 12.6 MB, a chain of eight ranks takes
         # 7 x (0.18 ms of wire at 70 GB/s + kernel + latency) + 3 x 0.18 = 2.4 ms from its first
-        # sweep to its last state -- hidden behind the two steps the engine keeps in flight -- at
+        # sweep to its last state -- hidden behind the `depth` steps the engine keeps in flight -- at
         # 16 point-to-point calls and 8 chain launches per rank and step.  (Round 2 ran eight
         # ranks with one scale per item and three groups, 36 calls: the host thread then needs
         # about as long per step as the device, scripts/experiments/slab_p2p_host_time.py.)
@@ -379,22 +407,27 @@ class SlabEngine:
         self.schedule = sweep_schedule(rank, world, len(self.items))
         f = lambda *shp: alloc(shp, "float32")
         self.pad_lo, self.pad_hi = overlap(rank, world)
-        # tc, cf with overlap, and the checkpoints: two sets, used by alternate steps, so that
-        # the prepass and the boundary sweeps of step t+1 (chain stream) may run while the bulk
-        # work of step t still reads its own -- in a stream of volumes the chains' start-up
-        # (W-1 hops) then hides behind the previous volume's X, Y and feature passes
-        self.src = [[f(self.pad_lo + nzl + self.pad_hi, ny, nx) for _ in range(nf)] for _ in range(2)]
-        # Z-pass output: written on the chain stream (fused kernels) while the X pass of the step
-        # before may still read its own, so it alternates between steps like src and ck
-        self.zo = [[[f(nzl, ny, nx) for _ in range(nf)] for _ in range(S)] for _ in range(2)]
+        # tc, cf with overlap, and the checkpoints: `depth` sets, used by successive steps in
+        # turn, so that the prepass and the lean sweeps of the next steps (chain stream) may run
+        # while the fused sweeps and the bulk work of step t still read their own -- in a stream of
+        # volumes the chains' start-up (W-1 hops) then hides behind the previous volumes' work
+        D = self.depth
+        self.src = [[f(self.pad_lo + nzl + self.pad_hi, ny, nx) for _ in range(nf)] for _ in range(D)]
+        # Z-pass output: written on the fused stream while the X pass of an earlier step may
+        # still read its own, so it rotates between steps like src and ck
+        self.zo = [[[f(nzl, ny, nx) for _ in range(nf)] for _ in range(S)] for _ in range(D)]
         self.xo = [[f(nzl, ny, nx) for _ in range(nf)] for _ in range(S)]   # X-pass output
         self.pad = [f(nzl + 2, ny, nx) for _ in range(S)]  # smoothed value S (Y output) + halo planes
         # the direction whose state reaches this rank first runs as a lean sweep, the other fused
         self.lean = 0 if rank <= world - 1 - rank else 1
+        # run() relies on it: the lean sweep of an item stands before its fused sweep
+        order = {di: k for k, di in enumerate(self.schedule)}
+        assert all(order[(self.lean, i)] < order[(1 - self.lean, i)] for i in range(len(self.items)))
         ckb = stages.ck_bytes((nzl, ny, nx))
-        self.ck = [[[alloc((ckb,), "uint8") for _ in range(nf)] for _ in range(S)] for _ in range(2)]
+        self.ck = [[[alloc((ckb,), "uint8") for _ in range(nf)] for _ in range(S)] for _ in range(D)]
         self.step = 0
-        self.free = [None, None]  # events: the bulk work that read src[p] / ck[p] has been enqueued and run
+        self.free = [None] * D    # events (bulk stream): the X pass that read zo[p] has run
+        self.fdone = [None] * D   # events (fused stream): the fused sweeps that read src[p] / ck[p] have run
         sb = lambda q, g: alloc((len(self.scale_groups[q]) * nf * STATE_BYTES_PER_LINE
                                  * self.groups[g][1],), "uint8")
         self.c_in = [sb(q, g) for q, g in self.items]
@@ -419,13 +452,14 @@ class SlabEngine:
         slab_shape = (self.nzl, self.ny, self.nx)
         on = sy.on if sy is not None else (lambda s: contextlib.nullcontext())
         chain = sy.chain if sy is not None else None
+        fstream = sy.fused if sy is not None else None
         bulk = sy.bulk if sy is not None else None
         post = sy.post if sy is not None else None
         rec = (lambda s: sy.record(s)) if sy is not None else (lambda s: None)
         wait = (lambda s, e: sy.wait(s, e)) if sy is not None else (lambda s, e: None)
         n = len(self.items)
 
-        par = self.step % 2
+        par = self.step % self.depth
         self.step += 1
         src, ck, zo = self.src[par], self.ck[par], self.zo[par]
 
@@ -440,21 +474,27 @@ class SlabEngine:
         # still travels under the sweep of item i.
         swept = [[None] * n, [None] * n]
         with on(chain):
-            wait(chain, self.free[par])  # the step before last has finished with this set
+            # this set was last used `depth` steps ago: its fused sweeps have read src and ck
+            # (its lean sweeps stand earlier in this very stream)
+            wait(chain, self.fdone[par])
             st.prepare(img_slab, mask_slab if self.has_mask else None, src[0],
                        src[1] if self.has_mask else None)
-            for d, i in self.schedule:
-                q, g = self.items[i]
-                ss = self.scale_groups[q]
-                l0, nl = self.groups[g]
-                has_nb = has_lo if d == 0 else has_hi
-                sin = (self.c_in if d == 0 else self.a_in)[i]
-                sout = (self.c_out if d == 0 else self.a_out)[i]
+        wait(fstream, self.free[par])  # ... and its X pass has read the Z output
+        last_fused = None
+        for d, i in self.schedule:
+            q, g = self.items[i]
+            ss = self.scale_groups[q]
+            l0, nl = self.groups[g]
+            has_nb = has_lo if d == 0 else has_hi
+            sin = (self.c_in if d == 0 else self.a_in)[i]
+            sout = (self.c_out if d == 0 else self.a_out)[i]
+            mine = chain if d == self.lean else fstream
+            with on(mine):
                 if has_nb:
                     with on(post):
                         wait(post, self.consumed[d][i])
                         rx = comm.irecv_up(sin) if d == 0 else comm.irecv_down(sin)
-                    rx.wait()   # the chain stream (RCCL) or the host (gloo) waits for the state
+                    rx.wait()   # this sweep's stream (RCCL) or the host (gloo) waits for the state
                 if self.sent[d][i] is not None:  # last step's send still reads sout
                     self.sent[d][i].wait()
                     self.sent[d][i] = None
@@ -464,14 +504,20 @@ class SlabEngine:
                 if d == self.lean:
                     st.z_sweep(d, srcs, self.pad_lo, self.nzl, sp, sgs, l0, nl, has_nb, sin, sout, cks)
                 else:  # its state arrives last: carried through the slab, the other from checkpoints
+                    # the lean sweep of the same item (it stands earlier in the schedule) has left
+                    # its checkpoints, and with it the prepass has run
+                    wait(fstream, swept[self.lean][i])
                     st.z_fused(d, srcs, self.pad_lo, self.nzl, [zo[s][k] for s in ss for k in range(nf)],
                                sp, sgs, l0, nl, has_lo, has_hi, sin, sout, cks)
-                swept[d][i] = rec(chain)
+                swept[d][i] = rec(mine)
                 self.consumed[d][i] = swept[d][i]
+                if d != self.lean:
+                    last_fused = swept[d][i]
                 if d == 0 and has_hi:
                     self.sent[d][i] = comm.isend_up(sout)
                 elif d == 1 and has_lo:
                     self.sent[d][i] = comm.isend_down(sout)
+        self.fdone[par] = last_fused
 
         first = 0 if has_lo else 1
         fat = 1 - self.lean
@@ -484,8 +530,7 @@ class SlabEngine:
             jobs = lambda bufs: [bufs[s][k] for s in ss for k in range(nf)]
             st.gaussian_axis_batch(jobs(zo), jobs(self.xo), sp, 0, sg)
             if qs is self.bulk_groups[-1]:
-                self.free[par] = rec(bulk)  # the last reader of this step's Z output (src and ck are
-                #                             only read on the chain stream, in order)
+                self.free[par] = rec(bulk)  # the last reader of this step's Z output
             own = [self.pad[s][1:self.nzl + 1] for s in ss]
             if nf == 2:  # the last pass stores numerator / denominator: one field from here on
                 st.gaussian_quotient([self.xo[s][0] for s in ss], [self.xo[s][1] for s in ss], own, sp, 1,
@@ -544,13 +589,17 @@ class SlabRunner:
         two = (world > 1 or bool(getattr(args, "force_slab", False))) and not os.environ.get("IFE_SLAB_ONE_STREAM")
         comm = NullComm() if proxy else TorchComm(dist, rank, world, device=dev)
         self.streams = _Streams(torch, dev, two_streams=two)  # IFE_SLAB_ONE_STREAM: diagnostics (clean per-kernel times)
+        if not comm.per_class or os.environ.get("IFE_SLAB_ONE_CHAIN"):  # (the variable: diagnostics)
+            self.streams.fused = self.streams.chain
         self.ctx = pkg.Context(dev.index or 0)
         self.ctx.set_stream(self.streams.bulk.cuda_stream)
-        self.chain_ctx = self.ctx
+        self.chain_ctx = self.fused_ctx = self.ctx
         if self.streams.chain is not self.streams.bulk:
             self.chain_ctx = pkg.Context(dev.index or 0)
             self.chain_ctx.set_stream(self.streams.chain.cuda_stream)
-        for c in {id(self.ctx): self.ctx, id(self.chain_ctx): self.chain_ctx}.values():
+            self.fused_ctx = pkg.Context(dev.index or 0)
+            self.fused_ctx.set_stream(self.streams.fused.cuda_stream)
+        for c in self.contexts():
             c.set_option(pkg.OPT_TRIG_MODE, args.trig)
             if getattr(args, "iir_block", None):
                 c.set_option(pkg.OPT_IIR_BLOCK, args.iir_block)
@@ -563,25 +612,26 @@ class SlabRunner:
             c.set_option(pkg.OPT_CONST_LINES, getattr(args, "const_lines", 0))
         dt = {"float32": torch.float32, "uint8": torch.uint8}
         alloc = lambda shp, d: torch.empty(shp, dtype=dt[d], device=dev)
-        self.engine = SlabEngine(HipStages(pkg, self.ctx, self.chain_ctx),
+        self.engine = SlabEngine(HipStages(pkg, self.ctx, self.chain_ctx, self.fused_ctx),
                                  comm, shape, spacing, sigmas, rank, world,
                                  alloc, layout, has_mask=self.d_mask is not None,
                                  streams=self.streams,
                                  line_groups=getattr(args, "line_groups", None),
-                                 scales_per_item=getattr(args, "scales_per_item", None))
+                                 scales_per_item=getattr(args, "scales_per_item", None),
+                                 depth=getattr(args, "slab_depth", None) or 3)
         # what was actually built, for the bench line
         if proxy:  # the state buffers are never received into: give them finite contents
             for b in self.engine.c_in + self.engine.a_in:
                 b.zero_()
         self.config = {"input": "int16" if i16 else "float32", "spacing": list(spacing),
-                       "slab_planes": nzl, "line_groups": len(self.engine.groups),
+                       "slab_planes": nzl, "line_groups": len(self.engine.groups), "depth": self.engine.depth,
                        "scales_per_item": len(self.engine.scale_groups[0])}
 
     def step(self):
         self.engine.run(self.d_img, self.d_mask, self.d_out)
 
     def contexts(self):
-        return [self.ctx] if self.chain_ctx is self.ctx else [self.ctx, self.chain_ctx]
+        return list({id(c): c for c in (self.ctx, self.chain_ctx, self.fused_ctx)}.values())
 
     def finish(self):
         self.engine.finish()
