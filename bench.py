@@ -121,7 +121,7 @@ def parse():
                          "out (slab.NullComm); `value` is then the whole volume over this rank's step")
     ap.add_argument("--proxy-rank", type=int, default=0)
     ap.add_argument("--slab-depth", type=int, default=None,
-                    help="slab engine: sets of per-step buffers = steps the boundary chain may run ahead (default 3)")
+                    help="slab engine: sets of per-step buffers = steps the boundary chain may run ahead (default 4)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: leave the per-kernel hipEvents out of the timed region (no kernel "
                          "table, no roofline.achieved from device time)")

@@ -341,7 +341,7 @@ class SlabEngine:
 
     def __init__(self, stages, comm, shape_zyx, spacing, sigmas, rank, world, alloc, layout,
                  has_mask=True, line_groups=None, bounds=None, streams=None,
-                 scales_per_item=None, depth=3):
+                 scales_per_item=None, depth=4):
         """alloc(shape, dtype_name) -> tensor ('float32' or 'uint8') on the compute device;
         bounds: W+1 plane indices (default: slab_bounds); line_groups: items per scale group on
         the boundary chains (default 4); scales_per_item: scales whose sweeps share a launch and a
@@ -352,7 +352,7 @@ class SlabEngine:
         checkpoints, Z output), i.e. how many steps the lean chain may run ahead of the bulk work:
         the chain of a step needs W-1 hops from end to end, and with d sets a step can be as short
         as that latency / d (eight ranks: ~2.4 ms predicted at 70 GB/s per link, 3.4 at 45; local
-        work 1.33 ms)."""
+        work 1.33 ms; scripts/experiments/slab_chain_sim.py: 3 sets suffice at 70 GB/s, 4 at 45)."""
         if depth < 2:
             raise ValueError("depth must be at least 2")
         self.depth = int(depth)
@@ -618,7 +618,7 @@ class SlabRunner:
                                  streams=self.streams,
                                  line_groups=getattr(args, "line_groups", None),
                                  scales_per_item=getattr(args, "scales_per_item", None),
-                                 depth=getattr(args, "slab_depth", None) or 3)
+                                 depth=getattr(args, "slab_depth", None) or 4)
         # what was actually built, for the bench line
         if proxy:  # the state buffers are never received into: give them finite contents
             for b in self.engine.c_in + self.engine.a_in:

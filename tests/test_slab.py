@@ -176,7 +176,7 @@ class OracleStages:
 
 
 def _worker(rank, world, port, shape, sigmas, spacing, use_hip, bounds, line_groups, steps, spi, edge_groups, ret,
-            i16=False, depth=3):
+            i16=False, depth=4):
     sys.path.insert(0, ROOT)
     os.environ["IFE_TRIG_MODE"] = "0"
     import torch
@@ -234,7 +234,7 @@ def _worker(rank, world, port, shape, sigmas, spacing, use_hip, bounds, line_gro
 
 
 def _run_world(world, shape, sigmas, spacing, use_hip, tmp_path, bounds=None, line_groups=None,
-               steps=1, spi=None, edge_groups=True, i16=False, depth=3):
+               steps=1, spi=None, edge_groups=True, i16=False, depth=4):
     import torch.multiprocessing as mp
     port = _free_port()
     mp.spawn(_worker, args=(world, port, shape, sigmas, spacing, use_hip, bounds, line_groups,
@@ -253,7 +253,7 @@ def _whole_volume(synth, shape, i16=False):
 @pytest.mark.parametrize("world,shape,spacing,bounds,groups,steps,spi,edge_groups", [
     (2, (16, 20, 12), (1.0, 1.0, 1.0), None, 1, 2, None, True),          # all scales in one item
     (3, (19, 40, 30), (1.0, 1.0, 1.0), [0, 4, 11, 19], 3, 1, 2, True),   # uneven cut, 3 line groups, scales 2 + 1
-    (4, (29, 24, 40), (0.8, 1.0, 1.25), None, 2, 5, 1, True),            # 8,7,7,7 planes, one scale per item; five steps: the three buffer sets reused
+    (4, (29, 24, 40), (0.8, 1.0, 1.25), None, 2, 6, 1, True),            # 8,7,7,7 planes, one scale per item; six steps: the four buffer sets reused
     (4, (16, 20, 24), (1.0, 1.0, 1.0), None, 2, 2, 1, False),            # everything on the default group
     (8, (37, 16, 40), (1.0, 1.0, 1.0), None, None, 2, None, True),       # eight ranks, the engine's own defaults there
     (5, (23, 16, 24), (1.0, 1.0, 1.0), [0, 4, 8, 13, 19, 23], 2, 2, None, True),  # odd world: the middle rank's directions tie
@@ -317,7 +317,7 @@ def test_slab_engine_rejects_thin_slabs(ife):
 def test_slab_engine_on_gpu_equals_single_gpu(ife, synth, tmp_path, world, shape, groups, spacing, i16, sigmas):
     """HIP stages, two streams per rank, ranks sharing the one GPU: bit-identical to the
     single-GPU path (which is itself compared with the oracle elsewhere)."""
-    got = _run_world(world, shape, sigmas, spacing, True, tmp_path, None, groups, 5, i16=i16)  # five steps: every buffer set reused
+    got = _run_world(world, shape, sigmas, spacing, True, tmp_path, None, groups, 6, i16=i16)  # six steps: every buffer set reused
     img, mask = _whole_volume(synth, shape, i16)
     with ife.Context(0) as c:
         c.set_option(ife.OPT_TRIG_MODE, 0)
@@ -366,7 +366,7 @@ def test_slab_engine_on_gpu_random_configurations(ife, synth, tmp_path):
         groups = int(rng.integers(1, 6))
         spi = None if rng.random() < 0.5 else 1
         steps = int(rng.integers(2, 8))
-        depth = int(rng.integers(2, 4))            # sets of per-step buffers: reused from step depth + 1 on
+        depth = int(rng.integers(2, 5))            # sets of per-step buffers: reused from step depth + 1 on
         sub = tmp_path / ("case%d" % case)
         sub.mkdir()
         what = "case %d: world %d shape %s bounds %s sigmas %s spacing %s groups %d spi %s steps %d depth %d" % (
