@@ -5,6 +5,7 @@ show() { python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().splitlines()[-1]); print('$1', d['ms_per_step'], {k:round(v['ms_per_step'],3) for k,v in d['roofline']['kernels'].items()})"; }
 run() { python3 bench.py --no-cpu-baseline --steps 20 --warmup 3 "$@" 2>gpurun_out/proxy.err; }
+shopt -s nullglob
 for rep in 1 2; do
   for lib in current scripts/experiments/libs/*.so; do
     [ "$lib" = current ] && unset IFE_HIP_LIB || export IFE_HIP_LIB=$lib
