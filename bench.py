@@ -504,6 +504,8 @@ def main():
                                          % (share, runner.config.get("line_groups", 1)),
                                          "" if runner.config["spacing"] == [1.0, 1.0, 1.0]
                                          else ", spacing %s" % runner.config["spacing"]),
+                   "slab_engine": ({k: runner.config[k] for k in ("slab_planes", "line_groups", "scales_per_item", "depth")}
+                                   if use_dist else None),
                    "iir_fma": 1 if args.iir_fma else 0,
                    "const_lines": args.const_lines,
                    "const_lines_meaning": "0: every line is filtered (every voxel pays the full path); "
