@@ -24,7 +24,7 @@ def schedule(rank, world, n):
 
 
 def simulate(W=8, steps=40, depth=3, split=True, G=4, wire=0.18, lat=0.03,
-             t_prep=0.038, t_lean=0.027, t_fused=0.057, t_x=0.285, t_rest=0.75, concurrent=False):
+             t_prep=0.038, t_lean=0.027, t_fused=0.057, t_x=0.285, t_rest=0.75, concurrent=False, halo=0.1):
     """concurrent=False: all kernels of a rank one at a time, not preempted (a sweep may wait
     behind a whole bulk kernel: pessimistic for the chain's latency); True: the chain kernels run
     beside the bulk kernels at no cost and the bulk kernels are stretched so that they alone fill
@@ -70,7 +70,12 @@ def simulate(W=8, steps=40, depth=3, split=True, G=4, wire=0.18, lat=0.03,
                     ops[("xfer", r, t, d, i)]["lat"] = lat
             lean_ = 0 if r <= W - 1 - r else 1
             add(("x", r, t), t_x, ("gpu", r), [("sweep", r, t, 1 - lean_, i) for i in range(G)], ("B", r), 1)
-            for k in range(3):   # Y and the feature launches: four kernels of the bulk stream
+            # Y, then the stencil planes of both neighbours' Y output (halo: one message each way,
+            # its own communicator), then the feature launches: four kernels of the bulk stream
+            add(("rest0", r, t), t_rest / 4, ("gpu", r), [], ("B", r), 1)
+            add(("halo", r, t), 0.0, ("nic", r), [("rest0", q, t) for q in (r - 1, r + 1) if 0 <= q < W], ("B", r), 1)
+            ops[("halo", r, t)]["lat"] = halo
+            for k in (1, 2):
                 add(("rest%d" % k, r, t), t_rest / 4, ("gpu", r), [], ("B", r), 1)
             add(("rest", r, t), t_rest / 4, ("gpu", r), [], ("B", r), 1)
 
