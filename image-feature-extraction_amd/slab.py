@@ -306,8 +306,8 @@ class NullComm:
 
 class _Streams:
     """The HIP streams of a rank on a GPU, or nothing on CPU: `bulk` (X, Y, features), `chain`
-    (prepass and the lean sweeps), `fused` (the fused sweeps), `post` (receives are posted from
-    it).  The lean and the fused sweeps have streams of their own because the fused sweeps of
+    (prepass and the lean sweeps), `fused` (the fused sweeps), `post[d]` (the receives of
+    direction d are posted from it).  The lean and the fused sweeps have streams of their own because the fused sweeps of
     step t wait for the state that arrives LAST -- on the end ranks after W-1 hops -- and the lean
     sweeps of step t+1, which START the next chain, must not queue behind that wait: in one
     in-order stream the two end ranks would hand the chains back and forth and a step would take
@@ -319,7 +319,9 @@ class _Streams:
         self.bulk = torch.cuda.current_stream(dev) if self.gpu else None
         self.chain = (torch.cuda.Stream(dev, priority=-1) if two_streams else self.bulk) if self.gpu else None
         self.fused = (torch.cuda.Stream(dev, priority=-1) if two_streams else self.bulk) if self.gpu else None
-        self.post = torch.cuda.Stream(dev) if self.gpu and two_streams else self.bulk
+        # one per direction: a stream of event waits is in order too, and the receive of a lean
+        # sweep must not stand behind the wait for a fused sweep of the step before
+        self.post = [torch.cuda.Stream(dev) if self.gpu and two_streams else self.bulk for _ in range(2)]
 
     def on(self, stream):
         return self.torch.cuda.stream(stream) if self.gpu else contextlib.nullcontext()
@@ -454,7 +456,7 @@ class SlabEngine:
         chain = sy.chain if sy is not None else None
         fstream = sy.fused if sy is not None else None
         bulk = sy.bulk if sy is not None else None
-        post = sy.post if sy is not None else None
+        post = sy.post if sy is not None else (None, None)
         rec = (lambda s: sy.record(s)) if sy is not None else (lambda s: None)
         wait = (lambda s, e: sy.wait(s, e)) if sy is not None else (lambda s, e: None)
         n = len(self.items)
@@ -468,7 +470,7 @@ class SlabEngine:
         # on the neighbour), so even if the runtime ran all streams of a rank through one
         # in-order hardware queue -- HIP shares a few queues among all streams -- a receive
         # that spins for its sender can only hold back work that comes after it in that order.
-        # It is issued from the `post` stream, which holds nothing but event waits: the
+        # It is issued from the direction's `post` stream, which holds nothing but event waits: the
         # communicator's stream then waits for the sweep that read the buffer in the previous
         # step and not for the sweeps queued on the chain stream, so the transfer of item i+1
         # still travels under the sweep of item i.
@@ -491,8 +493,8 @@ class SlabEngine:
             mine = chain if d == self.lean else fstream
             with on(mine):
                 if has_nb:
-                    with on(post):
-                        wait(post, self.consumed[d][i])
+                    with on(post[d]):
+                        wait(post[d], self.consumed[d][i])
                         rx = comm.irecv_up(sin) if d == 0 else comm.irecv_down(sin)
                     rx.wait()   # this sweep's stream (RCCL) or the host (gloo) waits for the state
                 if self.sent[d][i] is not None:  # last step's send still reads sout

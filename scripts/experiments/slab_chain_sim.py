@@ -24,7 +24,7 @@ def schedule(rank, world, n):
 
 
 def simulate(W=8, steps=40, depth=3, split=True, G=4, wire=0.18, lat=0.03,
-             t_prep=0.038, t_lean=0.027, t_fused=0.057, t_x=0.285, t_rest=0.75, concurrent=False, halo=0.1):
+             t_prep=0.038, t_lean=0.027, t_fused=0.057, t_x=0.285, t_rest=0.75, concurrent=False, halo=0.1, post_split=True):
     """concurrent=False: all kernels of a rank one at a time, not preempted (a sweep may wait
     behind a whole bulk kernel: pessimistic for the chain's latency); True: the chain kernels run
     beside the bulk kernels at no cost and the bulk kernels are stretched so that they alone fill
@@ -56,6 +56,13 @@ def simulate(W=8, steps=40, depth=3, split=True, G=4, wire=0.18, lat=0.03,
             for d, i in schedule(r, W, G):
                 src = r - 1 if d == 0 else r + 1          # where the state comes from
                 has_nb = 0 <= src < W
+                if has_nb:
+                    # the receive is posted from an in-order stream of event waits: once the sweep
+                    # of the step before has consumed the buffer (post_split: one such stream per
+                    # direction, else one for both -- a lean receive then queues behind the wait
+                    # for a fused sweep of the step before)
+                    add(("post", r, t, d, i), 0.0, ("none", r, t, d, i), [("sweep", r, t - 1, d, i)],
+                        ("P", r, d if post_split else 0), 0)
                 deps = [("xfer", src, t, d, i)] if has_nb else []
                 deps.append(("xfer", r, t - 1, d, i))     # the record of the step before has left the out buffer
                 if d == lean:
@@ -66,7 +73,7 @@ def simulate(W=8, steps=40, depth=3, split=True, G=4, wire=0.18, lat=0.03,
                 dst = r + 1 if d == 0 else r - 1
                 if 0 <= dst < W:   # the record leaves once swept and once the receiver has consumed the last one
                     add(("xfer", r, t, d, i), wire, ("link", min(r, dst), d),
-                        [("sweep", r, t, d, i), ("sweep", dst, t - 1, d, i)], ("N", r, d), 0)
+                        [("sweep", r, t, d, i), ("post", dst, t, d, i)], ("N", r, d), 0)
                     ops[("xfer", r, t, d, i)]["lat"] = lat
             lean_ = 0 if r <= W - 1 - r else 1
             add(("x", r, t), t_x, ("gpu", r), [("sweep", r, t, 1 - lean_, i) for i in range(G)], ("B", r), 1)
@@ -110,9 +117,10 @@ if __name__ == "__main__":
         kw = dict(t_prep=0.038 * f, t_lean=0.027 * f, t_fused=0.057 * f, t_x=0.285 * f, t_rest=0.75 * f)
         for wire in (0.18, 0.28):
             row = []
-            for split, depth in ((False, 2), (True, 2), (True, 3), (True, 4)):
-                a = simulate(W=W, depth=depth, split=split, wire=wire, **kw)
-                b = simulate(W=W, depth=depth, split=split, wire=wire, concurrent=True, **kw)
-                row.append("%s depth %d: %.2f / %.2f" % ("two chain streams" if split else "one chain stream ", depth, a, b))
+            for split, depth, ps in ((False, 2, False), (True, 4, False), (True, 2, True), (True, 3, True), (True, 4, True)):
+                a = simulate(W=W, depth=depth, split=split, wire=wire, post_split=ps, **kw)
+                b = simulate(W=W, depth=depth, split=split, wire=wire, concurrent=True, post_split=ps, **kw)
+                row.append("%s, %s, depth %d: %.2f / %.2f" % ("two chain streams" if split else "one chain stream ",
+                                                             "receives posted per direction" if ps else "one posting stream", depth, a, b))
             print("W=%d  item on the wire %.2f ms | " % (W, wire) + " | ".join(row))
     sys.stdout.flush()
