@@ -29,13 +29,16 @@ import numpy as np
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_VOXEL_SCALE = 37  # 4 (image) + 1 (mask) + 8*4 (out)
 
-# N > 1: a rank drives nine streams (bulk, boundary chain, receive posting, and RCCL's own
-# stream per edge and traffic class).  HIP multiplexes streams onto GPU_MAX_HW_QUEUES
-# hardware queues (default 4), and a receive kernel that spins for its neighbour would hold
-# back whatever shares its queue; the slab engine's enqueue order keeps that free of deadlock
-# (slab.py), a queue per stream keeps it free of false waits too.  Read when the HIP runtime
-# starts, so it is set before anything touches the GPU; the caller's own value wins.
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+# Slab engine: a rank drives eleven streams (bulk, lean chain, fused chain, two for posting
+# receives, and RCCL's own stream per edge and traffic class).  HIP multiplexes streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams that share a queue are in order
+# with each other: a receive that waits for its neighbour would hold back whatever shares its
+# queue, and the lean chain could no longer run ahead of the fused one.  The engine's enqueue
+# order keeps that free of deadlock (slab.py); a queue per stream keeps it free of false waits
+# (scripts/experiments/stream_independence_probe.py: independent at 16, not at 4).  Read when
+# the HIP runtime starts, so it is set before anything touches the GPU; the caller's own value
+# wins.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or any(a in sys.argv for a in ("--force-slab", "--proxy-world")):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -591,7 +591,11 @@ class SlabRunner:
         two = (world > 1 or bool(getattr(args, "force_slab", False))) and not os.environ.get("IFE_SLAB_ONE_STREAM")
         comm = NullComm() if proxy else TorchComm(dist, rank, world, device=dev)
         self.streams = _Streams(torch, dev, two_streams=two)  # IFE_SLAB_ONE_STREAM: diagnostics (clean per-kernel times)
-        if not comm.per_class or os.environ.get("IFE_SLAB_ONE_CHAIN"):  # (the variable: diagnostics)
+        # Two ranks: a chain is one hop long, nothing to run ahead of -- and lean and fused sweeps
+        # running side by side cost the local work 5-7 % (interior rank of eight: 1.46-1.50 ms per
+        # step against 1.38 in one stream; stream priorities make no difference), which only a
+        # longer chain pays back (simulated: 2.65 -> 1.45 ms per step at eight ranks, 2.9 -> 2.65 at four).
+        if not comm.per_class or world <= 2 or os.environ.get("IFE_SLAB_ONE_CHAIN"):  # (the variable: diagnostics)
             self.streams.fused = self.streams.chain
         self.ctx = pkg.Context(dev.index or 0)
         self.ctx.set_stream(self.streams.bulk.cuda_stream)
