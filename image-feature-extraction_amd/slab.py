@@ -307,11 +307,11 @@ class NullComm:
 class _Streams:
     """The HIP streams of a rank on a GPU, or nothing on CPU: `bulk` (X, Y, features), `chain`
     (prepass and the lean sweeps), `fused` (the fused sweeps), `post[d]` (the receives of
-    direction d are posted from it).  The lean and the fused sweeps have streams of their own because the fused sweeps of
-    step t wait for the state that arrives LAST -- on the end ranks after W-1 hops -- and the lean
-    sweeps of step t+1, which START the next chain, must not queue behind that wait: in one
-    in-order stream the two end ranks would hand the chains back and forth and a step would take
-    a whole chain latency however little work it holds."""
+    direction d are posted from it).  The lean and the fused sweeps have streams of their own
+    because the fused sweeps of step t wait for the state that arrives LAST -- on the end ranks
+    after W-1 hops -- and the lean sweeps of step t+1, which START the next chain, must not queue
+    behind that wait: in one in-order stream the two end ranks would hand the chains back and
+    forth and a step would take a whole chain latency however little work it holds."""
 
     def __init__(self, torch, dev, two_streams):
         self.torch = torch
