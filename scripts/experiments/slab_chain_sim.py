@@ -24,7 +24,7 @@ def schedule(rank, world, n):
 
 
 def simulate(W=8, steps=40, depth=3, split=True, G=4, wire=0.18, lat=0.03,
-             t_prep=0.038, t_lean=0.027, t_fused=0.057, t_x=0.285, t_rest=0.75, concurrent=False, halo=0.1, post_split=True):
+             t_prep=0.038, t_lean=0.027, t_fused=0.057, t_x=0.285, t_rest=0.75, concurrent=False, halo=0.1, post_split=True, skew=False):
     """concurrent=False: all kernels of a rank one at a time, not preempted (a sweep may wait
     behind a whole bulk kernel: pessimistic for the chain's latency); True: the chain kernels run
     beside the bulk kernels at no cost and the bulk kernels are stretched so that they alone fill
@@ -47,45 +47,32 @@ def simulate(W=8, steps=40, depth=3, split=True, G=4, wire=0.18, lat=0.03,
         ops[name] = dict(dur=dur, res=res, deps=deps, prio=prio)
         order.append(name)
 
+    def lean_of(r):
+        return 0 if r <= W - 1 - r else 1
+
     for t in range(steps):
         for r in range(W):
-            lean = 0 if r <= W - 1 - r else 1
+            lean = lean_of(r)
             sL = ("L", r)
             sF = ("F", r) if split else sL
-            add(("prep", r, t), t_prep, chain_res(r), [("sweep", r, t - depth, 1 - lean, G - 1)], sL, 0)
-            for d, i in schedule(r, W, G):
-                src = r - 1 if d == 0 else r + 1          # where the state comes from
-                has_nb = 0 <= src < W
-                if has_nb:
-                    # the receive is posted from an in-order stream of event waits: once the sweep
-                    # of the step before has consumed the buffer (post_split: one such stream per
-                    # direction, else one for both -- a lean receive then queues behind the wait
-                    # for a fused sweep of the step before)
-                    add(("post", r, t, d, i), 0.0, ("none", r, t, d, i), [("sweep", r, t - 1, d, i)],
-                        ("P", r, d if post_split else 0), 0)
-                deps = [("xfer", src, t, d, i)] if has_nb else []
-                deps.append(("xfer", r, t - 1, d, i))     # the record of the step before has left the out buffer
-                if d == lean:
-                    add(("sweep", r, t, d, i), t_lean, chain_res(r), deps, sL, 0)
-                else:
-                    deps += [("sweep", r, t, lean, i), ("x", r, t - depth)]
-                    add(("sweep", r, t, d, i), t_fused, chain_res(r), deps, sF, 0)
-                dst = r + 1 if d == 0 else r - 1
-                if 0 <= dst < W:   # the record leaves once swept and once the receiver has consumed the last one
-                    add(("xfer", r, t, d, i), wire, ("link", min(r, dst), d),
-                        [("sweep", r, t, d, i), ("post", dst, t, d, i)], ("N", r, d), 0)
-                    ops[("xfer", r, t, d, i)]["lat"] = lat
-            lean_ = 0 if r <= W - 1 - r else 1
-            add(("x", r, t), t_x, ("gpu", r), [("sweep", r, t, 1 - lean_, i) for i in range(G)], ("B", r), 1)
-            # Y, then the stencil planes of both neighbours' Y output (halo: one message each way,
-            # its own communicator), then the feature launches: four kernels of the bulk stream
-            add(("rest0", r, t), t_rest / 4, ("gpu", r), [], ("B", r), 1)
-            add(("halo", r, t), 0.0, ("nic", r), [("rest0", q, t) for q in (r - 1, r + 1) if 0 <= q < W], ("B", r), 1)
-            ops[("halo", r, t)]["lat"] = halo
-            for k in (1, 2):
-                add(("rest%d" % k, r, t), t_rest / 4, ("gpu", r), [], ("B", r), 1)
-            add(("rest", r, t), t_rest / 4, ("gpu", r), [], ("B", r), 1)
-
+            # skew (one chain stream, software-pipelined by one step): the stream holds, per step,
+            # the prepass and the lean sweeps of step t+1 interleaved with the fused sweeps of step t
+            if skew and t == 0:
+                add(("prep", r, 0), t_prep, chain_res(r), [], sL, 0)
+            tp = t + 1 if skew else t
+            if tp < steps:
+                add(("prep", r, tp), t_prep, chain_res(r), [("sweep", r, tp - depth, 1 - lean, G - 1)], sL, 0)
+            sched = schedule(r, W, G)
+            if skew and t == 0:   # the very first lean sweeps
+                sched = [(d, i, 0) for d, i in sched if d == lean] + [(d, i, (1 if d == lean else 0)) for d, i in sched]
+            else:
+                sched = [(d, i, (t + 1 if (skew and d == lean) else t)) for d, i in sched]
+            for d, i, t_ in sched:
+                if t_ >= steps:
+                    continue
+                _emit_sweep(add, ops, r, t_, d, i, lean, W, G, depth, sL, sF, chain_res, t_lean, t_fused, wire, lat, post_split)
+            add(("x", r, t), t_x, ("gpu", r), [("sweep", r, t, 1 - lean, i) for i in range(G)], ("B", r), 1)
+            _emit_rest(add, ops, r, t, W, t_rest, halo)
     for o in ops.values():   # dependencies on steps before the first one do not exist
         o["deps"] = [d for d in o["deps"] if d in ops]
     finish, res_free, pending = {}, {}, list(order)
@@ -107,6 +94,40 @@ def simulate(W=8, steps=40, depth=3, split=True, G=4, wire=0.18, lat=0.03,
     done = [max(finish[("rest", r, t)] for r in range(W)) for t in range(steps)]
     k = steps // 2
     return (done[-1] - done[k]) / (steps - 1 - k)
+
+
+def _emit_sweep(add, ops, r, t, d, i, lean, W, G, depth, sL, sF, chain_res, t_lean, t_fused, wire, lat, post_split):
+    src = r - 1 if d == 0 else r + 1          # where the state comes from
+    has_nb = 0 <= src < W
+    if has_nb:
+        # the receive is posted from an in-order stream of event waits: once the sweep of the step
+        # before has consumed the buffer (post_split: one such stream per direction, else one for
+        # both -- a lean receive then queues behind the wait for a fused sweep of the step before)
+        add(("post", r, t, d, i), 0.0, ("none", r, t, d, i), [("sweep", r, t - 1, d, i)],
+            ("P", r, d if post_split else 0), 0)
+    deps = [("xfer", src, t, d, i)] if has_nb else []
+    deps.append(("xfer", r, t - 1, d, i))     # the record of the step before has left the out buffer
+    if d == lean:
+        add(("sweep", r, t, d, i), t_lean, chain_res(r), deps, sL, 0)
+    else:
+        deps += [("sweep", r, t, lean, i), ("x", r, t - depth)]
+        add(("sweep", r, t, d, i), t_fused, chain_res(r), deps, sF, 0)
+    dst = r + 1 if d == 0 else r - 1
+    if 0 <= dst < W:   # the record leaves once swept and once the receiver has posted its receive
+        add(("xfer", r, t, d, i), wire, ("link", min(r, dst), d),
+            [("sweep", r, t, d, i), ("post", dst, t, d, i)], ("N", r, d), 0)
+        ops[("xfer", r, t, d, i)]["lat"] = lat
+
+
+def _emit_rest(add, ops, r, t, W, t_rest, halo):
+    # Y, then the stencil planes of both neighbours' Y output (halo: one message each way, its own
+    # communicator), then the feature launches: four kernels of the bulk stream
+    add(("rest0", r, t), t_rest / 4, ("gpu", r), [], ("B", r), 1)
+    add(("halo", r, t), 0.0, ("nic", r), [("rest0", q, t) for q in (r - 1, r + 1) if 0 <= q < W], ("B", r), 1)
+    ops[("halo", r, t)]["lat"] = halo
+    for k in (1, 2):
+        add(("rest%d" % k, r, t), t_rest / 4, ("gpu", r), [], ("B", r), 1)
+    add(("rest", r, t), t_rest / 4, ("gpu", r), [], ("B", r), 1)
 
 
 if __name__ == "__main__":
