@@ -348,10 +348,16 @@ def test_slab_engine_full_size_equals_single_gpu(ife, synth, tmp_path):
 def test_slab_engine_on_gpu_random_configurations(ife, synth, tmp_path):
     """The Python engine (what bench.py runs at N > 1) on drawn configurations: 2-5 ranks sharing
     the GPU, awkward shapes, uneven cuts, 1-5 line groups, one or all scales per item, two or
-    three steps -- identical bits to the single-GPU path.  IFE_FUZZ_CASES / 6 cases (default 4)."""
-    ncases = max(1, int(os.environ.get("IFE_FUZZ_CASES", "24")) // 6)
+    three steps -- identical bits to the single-GPU path.  IFE_FUZZ_CASES / 6 cases (default 4, at most 60)."""
+    # at most 60: every case starts 2-5 processes (~5 s), and a test that prints nothing for seven
+    # minutes is taken for hung on the GPU box -- hence also the progress file under gpurun_out/
+    ncases = min(60, max(1, int(os.environ.get("IFE_FUZZ_CASES", "24")) // 6))
     rng = np.random.default_rng(int(os.environ.get("IFE_FUZZ_SEED", "20261004")) + 7)
+    progress = os.path.join(ROOT, "gpurun_out", "slab_random_progress.log") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None
     for case in range(ncases):
+        if progress:
+            with open(progress, "a") as fh:
+                fh.write("case %d of %d\n" % (case, ncases))
         world = int(rng.integers(2, 6))
         ny, nx = int(rng.choice([4, 9, 20, 33, 64, 70])), int(rng.choice([4, 12, 31, 64, 100]))
         nz = 4 * world + int(rng.integers(0, 40))
